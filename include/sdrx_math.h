@@ -1,0 +1,168 @@
+/*
+ * sdrx_math.h -- portable, bit-reproducible fp64 sincos / atan2.
+ *
+ * Why this exists: the reference's PSK carrier loop calls libm cos/sin per
+ * sample (RadioNode/src/libraries/streams/BPSK.cpp:403-404, QPSK.cpp:365-366)
+ * and the phase-difference FM discriminator calls libm atan2
+ * (RadioNode/third-party/RTLSDR/rtl_fm.c:428-435).  glibc on the host and
+ * ocml on the GPU do not return bit-identical results for those, and the
+ * loops feed hard decisions, so the device path and its CPU checker must use
+ * ONE definition.  Everything below is built only from IEEE-754 +,-,*,/ ,
+ * rint and comparisons, evaluated in source order; compile it with
+ * -ffp-contract=off on every target (gcc for the host, hipcc for gfx950) and
+ * the two sides agree to the last bit.  Accuracy against libm: <= 2 ulp on
+ * the reduced range, |x| < 1.6e6 for sincos (the oracle's libm mode measures
+ * the distance; see tests/test_oracle_golden.py).
+ *
+ * Polynomial coefficients and the split-pi constants are the classic
+ * fdlibm / FreeBSD msun ones (Copyright (C) 1993 by Sun Microsystems, Inc.
+ * "Permission to use, copy, modify, and distribute this software is freely
+ * granted, provided that this notice is preserved.").  The evaluation code is
+ * written for this project.
+ */
+#ifndef SDRX_MATH_H
+#define SDRX_MATH_H
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define SDRX_HD __host__ __device__ static inline
+#else
+#define SDRX_HD static inline
+#endif
+
+/* ---- sincos ------------------------------------------------------------- */
+
+/* sin(r) on |r| <= pi/4 */
+SDRX_HD double sdrx_ksin(double r)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = r * r;
+    double p = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    double v = z * r;
+    return r + v * (S1 + z * p);
+}
+
+/* cos(r) on |r| <= pi/4 */
+SDRX_HD double sdrx_kcos(double r)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = r * r;
+    double p = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    double hz = 0.5 * z;
+    double w = 1.0 - hz;
+    /* (1 - hz) - w is the rounding error of w, recovered exactly */
+    return w + (((1.0 - w) - hz) + z * p);
+}
+
+/* s = sin(x), c = cos(x).  Same bits on every IEEE-754 target. */
+SDRX_HD void sdrx_sincos(double x, double *s, double *c)
+{
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    /* pi/2 split in 33-bit pieces: fn*P1 and fn*P2 are exact for |fn| < 2^20 */
+    const double P1 = 1.57079632673412561417e+00, P2 = 6.07710050630396597660e-11,
+                 P3 = 2.02226624871116645580e-21, P3T = 8.47842766036889956997e-32;
+    /* 2^20 * 2*pi split in three pieces with 26 trailing zero bits each (coarse stage for huge |x|) */
+    const double M1 = 6588397.0, M2 = 0.31666114181280136 /* 0x1.4442d18p-2 */, M3 = 2.56827048412547e-10;
+    double ax = x < 0.0 ? -x : x;
+    if (!(ax < 1.0e300)) { /* inf / nan / absurd */
+        *s = x - x;
+        *c = x - x;
+        return;
+    }
+    if (ax > 1.5e6) {
+        double q = rint(x * 1.5178198155583891e-07); /* 1/(2^20*2pi) */
+        x = ((x - q * M1) - q * M2) - q * M3;
+    }
+    double fn = rint(x * INV_PIO2);
+    double r = ((x - fn * P1) - fn * P2) - fn * P3;
+    r = r - fn * P3T;
+    long long n = (long long)fn;
+    double sr = sdrx_ksin(r);
+    double cr = sdrx_kcos(r);
+    switch ((int)(n & 3)) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+    }
+}
+
+/* ---- atan / atan2 ------------------------------------------------------- */
+
+/* atan(x) for x >= 0, finite */
+SDRX_HD double sdrx_atan_pos(double x)
+{
+    const double HI0 = 4.63647609000806093515e-01, HI1 = 7.85398163397448278999e-01,
+                 HI2 = 9.82793723247329054082e-01, HI3 = 1.57079632679489655800e+00;
+    const double LO0 = 2.26987774529616870924e-17, LO1 = 3.06161699786838301793e-17,
+                 LO2 = 1.39033110312309984516e-17, LO3 = 6.12323399573676603587e-17;
+    const double A0 = 3.33333333333329318027e-01, A1 = -1.99999999998764832476e-01,
+                 A2 = 1.42857142725034663711e-01, A3 = -1.11111104054623557880e-01,
+                 A4 = 9.09088713343650656196e-02, A5 = -7.69187620504482999495e-02,
+                 A6 = 6.66107313738753120669e-02, A7 = -5.83357013379057348645e-02,
+                 A8 = 4.97687799461593236017e-02, A9 = -3.65315727442169155270e-02,
+                 A10 = 1.62858201153657823623e-02;
+    double hi, lo, t;
+    int red;
+    if (x >= 7.378697629483821e19) /* 2^66 */
+        return HI3 + LO3;
+    if (x < 0.4375) {
+        red = 0; hi = 0.0; lo = 0.0; t = x;
+    } else if (x < 0.6875) {
+        red = 1; hi = HI0; lo = LO0; t = (2.0 * x - 1.0) / (2.0 + x);
+    } else if (x < 1.1875) {
+        red = 1; hi = HI1; lo = LO1; t = (x - 1.0) / (x + 1.0);
+    } else if (x < 2.4375) {
+        red = 1; hi = HI2; lo = LO2; t = (x - 1.5) / (1.0 + 1.5 * x);
+    } else {
+        red = 1; hi = HI3; lo = LO3; t = -1.0 / x;
+    }
+    double z = t * t;
+    double w = z * z;
+    double s1 = z * (A0 + w * (A2 + w * (A4 + w * (A6 + w * (A8 + w * A10)))));
+    double s2 = w * (A1 + w * (A3 + w * (A5 + w * (A7 + w * A9))));
+    if (!red)
+        return t - t * (s1 + s2);
+    return hi - ((t * (s1 + s2) - lo) - t);
+}
+
+/* atan2(y, x), C99 sign/zero conventions for finite inputs; nan in -> nan out. */
+SDRX_HD double sdrx_atan2(double y, double x)
+{
+    const double PI = 3.1415926535897931160e+00, PI_LO = 1.2246467991473531772e-16;
+    const double PIO2 = 1.5707963267948965580e+00;
+    if (x != x || y != y)
+        return x + y;
+    int yneg = (y < 0.0) || (y == 0.0 && 1.0 / y < 0.0);
+    int xneg = (x < 0.0) || (x == 0.0 && 1.0 / x < 0.0);
+    if (y == 0.0) {
+        if (!xneg) return y;          /* +-0 */
+        return yneg ? -PI : PI;
+    }
+    if (x == 0.0)
+        return yneg ? -PIO2 : PIO2;
+    double ay = yneg ? -y : y;
+    double ax = xneg ? -x : x;
+    double z;
+    int xinf = ax > 1.79769313486231570815e+308;
+    int yinf = ay > 1.79769313486231570815e+308;
+    if (xinf || yinf) {
+        if (xinf && yinf) z = 7.85398163397448278999e-01;
+        else if (yinf) z = PIO2;
+        else z = 0.0;
+    } else {
+        z = sdrx_atan_pos(ay / ax);
+    }
+    if (!xneg)
+        return yneg ? -z : z;
+    /* second / third quadrant: pi - z, carrying pi's tail */
+    z = PI - (z - PI_LO);
+    return yneg ? -z : z;
+}
+
+#endif /* SDRX_MATH_H */

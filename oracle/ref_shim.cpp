@@ -1,0 +1,182 @@
+// ref_shim.cpp -- extern "C" handles onto the REFERENCE's own classes.
+//
+// TEST INFRASTRUCTURE ONLY.  This file contains no reference code: it includes the
+// reference headers where they lie under /root/reference and is linked against the
+// reference's own .cpp files by oracle/Makefile into oracle/_ref/libsdr_ref.so
+// (git-ignored; outputs only).  tests/test_oracle_vs_ref.py uses it to validate the
+// C restatement (sdr_oracle.c) bit-for-bit, and gen_fixtures.py to dump fixtures.
+// streams/FM.h does not compile as shipped and is NOT built here;
+// the FM restatement is pinned by the reference's TEST_FM golden vectors instead.
+#include <cstring>
+#include <cstdint>
+#include <cstdio>
+
+#include <FIR-filter-class/filt.h>
+#include <streams/AM.h>
+#include <streams/BPSK.h>
+#include <streams/QPSK.h>
+#include <DigitalSignalProcessing/Resample.h>
+#include <common/BBP_Block.h>
+
+extern "C" {
+
+// ---- Filter ----
+void *ref_fir_new(int type, int two_freq, int taps, double Fs, double Fx, double Fu)
+{
+    if (two_freq) return new Filter((filterType)type, taps, Fs, Fx, Fu);
+    return new Filter((filterType)type, taps, Fs, Fx);
+}
+int ref_fir_error(void *h) { return ((Filter *)h)->get_error_flag(); }
+void ref_fir_get_taps(void *h, double *taps) { ((Filter *)h)->get_taps(taps); }
+void ref_fir_execute(void *h, double *buf, size_t n) { ((Filter *)h)->execute(buf, n); }
+double ref_fir_do_sample(void *h, double x) { return ((Filter *)h)->do_sample(x); }
+void ref_fir_init(void *h) { ((Filter *)h)->init(); }
+// The error-path constructor leaves m_taps/m_sr uninitialised and the destructor frees
+// them (filt.cpp:54-58,104-108): leak errored objects instead of crashing the checker.
+void ref_fir_free(void *h) { if (((Filter *)h)->get_error_flag() == 0) delete (Filter *)h; }
+
+// ---- AM ----
+void ref_am_modulate(uint8_t *bits, size_t len, double *out, size_t len_mod)
+{
+    AM<RADIO_DATA_TYPE> am;
+    am.modulate(bits, len, out, nullptr, len_mod);
+}
+size_t ref_am_demodulate(double *re, double *im, uint8_t *out, size_t n, size_t ds)
+{
+    AM<RADIO_DATA_TYPE> am;
+    return am.demodulate(re, im, out, n, ds);
+}
+
+// ---- Resample ----
+size_t ref_decimate(double *block, size_t len, size_t by) { return decimate<RADIO_DATA_TYPE>(block, len, by); }
+size_t ref_upsample_fill_w_zeros(double *in, size_t in_len, double *out, size_t out_len, double ratio)
+{
+    return upsample_fill_w_zeros(in, in_len, out, out_len, ratio);
+}
+
+// ---- BPSK ----
+void *ref_bpsk_new(uint64_t uw, size_t uw_len) { return new BPSK(uw, uw_len); }
+void ref_bpsk_free(void *h) { delete (BPSK *)h; }
+void ref_bpsk_modulate(void *h, uint8_t *bits, size_t len, double *out, size_t len_mod)
+{
+    ((BPSK *)h)->modulate(bits, len, out, len_mod);
+}
+static void load_block(BBP_Block &b, const double *iq, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        b.points[i].real(iq[2 * i]);
+        b.points[i].imag(iq[2 * i + 1]);
+        b.n_points++;
+    }
+}
+size_t ref_bpsk_demodulate(void *h, const double *iq, size_t n, double *out_re, double *out_im)
+{
+    BBP_Block in(n ? n : 1), out(n ? n : 1);
+    load_block(in, iq, n);
+    ((BPSK *)h)->demodulate(&in, &out);
+    for (size_t i = 0; i < out.n_points; i++) {
+        out_re[i] = out.points[i].real();
+        if (out_im) out_im[i] = out.points[i].imag();
+    }
+    return out.n_points;
+}
+size_t ref_bpsk_decode_pulse_shape(void *h, const double *iq, size_t n, double *re, double *im)
+{
+    BBP_Block in(n ? n : 1);
+    load_block(in, iq, n);
+    return ((BPSK *)h)->decode_pulseShape(&in, re, im);
+}
+void ref_bpsk_timing(void *h, double *re, double *im, size_t n) { ((BPSK *)h)->symbol_timing_synchronization(re, im, n); }
+size_t ref_bpsk_phase(void *h, double *re, double *im, size_t n) { return ((BPSK *)h)->phase_shift_correction(re, im, n); }
+void ref_bpsk_ambiguity(void *h, double *re, size_t n) { ((BPSK *)h)->phase_ambiguity_correction(re, nullptr, n); }
+// state dump in the order of orc_psk's leading doubles (sdr_oracle.h)
+void ref_bpsk_state(void *h, double *s, int32_t *cc)
+{
+    BPSK *b = (BPSK *)h;
+    int k = 0;
+    s[k++] = b->NcoControlVariables.delay;
+    s[k++] = b->Register_mu;
+    s[k++] = b->Register_Q;
+    s[k++] = b->Register_I;
+    s[k++] = b->SymbolTimingSynchronizationVariables.muDelay;
+    const BPSK::InterpData *ip[2] = {&b->Interp_Q_Channel, &b->Interp_I_Channel};
+    for (int c = 0; c < 2; c++) {
+        s[k++] = ip[c]->delay1; s[k++] = ip[c]->delay2; s[k++] = ip[c]->delay3;
+        s[k++] = ip[c]->delay4; s[k++] = ip[c]->delay5;
+    }
+    s[k++] = b->GardnerDetectorVariables.delay1; s[k++] = b->GardnerDetectorVariables.delay2;
+    s[k++] = b->GardnerDetectorVariables.delay3; s[k++] = b->GardnerDetectorVariables.delay4;
+    s[k++] = b->LoopFilterVariables.delay_x; s[k++] = b->LoopFilterVariables.delay_y;
+    s[k++] = b->PhaseCorrectionVariables.dds_delay;
+    s[k++] = b->PhaseLoopFilterVariables.delay_x; s[k++] = b->PhaseLoopFilterVariables.delay_y;
+    cc[0] = b->m_phase_ambiguity_cc.value();
+    cc[1] = cc[2] = cc[3] = 5;
+}
+
+// ---- QPSK ----
+void *ref_qpsk_new(const double *uw64, size_t uw_len)
+{
+    return uw64 ? new QPSK(uw64, uw_len) : new QPSK(QPSK::DEFAULT_UNIQUE_WORD, uw_len);
+}
+void ref_qpsk_free(void *h) { delete (QPSK *)h; }
+void ref_qpsk_modulate(void *h, uint8_t *sym, size_t len, double *out_re, double *out_im, size_t len_mod)
+{
+    ((QPSK *)h)->modulate(sym, len, out_re, out_im, len_mod);
+}
+size_t ref_qpsk_demodulate(void *h, const double *iq, size_t n, double *out_re, double *out_im)
+{
+    BBP_Block in(n ? n : 1), out(n ? n : 1);
+    load_block(in, iq, n);
+    ((QPSK *)h)->demodulate(&in, &out);
+    for (size_t i = 0; i < out.n_points; i++) {
+        out_re[i] = out.points[i].real();
+        if (out_im) out_im[i] = out.points[i].imag();
+    }
+    return out.n_points;
+}
+// stage-wise driver: which = 0 decode (iq,n -> re,im; returns n/4), 1 timing, 2 phase, 3 ambiguity
+size_t ref_qpsk_stage(void *h, int which, const double *iq, double *re, double *im, size_t n)
+{
+    QPSK *q = (QPSK *)h;
+    if (which == 0) {
+        BBP_Block in(n ? n : 1);
+        load_block(in, iq, n);
+        q->m_length = n / 4;
+        q->m_RealData = re;
+        q->m_ImagData = im;
+        return q->decode_pulseShape(&in);
+    }
+    q->m_length = n;
+    q->m_RealData = re;
+    q->m_ImagData = im;
+    if (which == 1) q->symbol_timing_synchronization();
+    else if (which == 2) q->phase_shift_correction();
+    else q->phase_ambiguity_correction();
+    return q->m_length;
+}
+void ref_qpsk_state(void *h, double *s, int32_t *cc)
+{
+    QPSK *b = (QPSK *)h;
+    int k = 0;
+    s[k++] = b->NcoControlVariables.delay;
+    s[k++] = b->Register_mu;
+    s[k++] = b->Register_Q;
+    s[k++] = b->Register_I;
+    s[k++] = b->SymbolTimingSynchronizationVariables.muDelay;
+    const QPSK::InterpData *ip[2] = {&b->Interp_Q_Channel, &b->Interp_I_Channel};
+    for (int c = 0; c < 2; c++) {
+        s[k++] = ip[c]->delay1; s[k++] = ip[c]->delay2; s[k++] = ip[c]->delay3;
+        s[k++] = ip[c]->delay4; s[k++] = ip[c]->delay5;
+    }
+    s[k++] = b->GardnerDetectorVariables.delay1; s[k++] = b->GardnerDetectorVariables.delay2;
+    s[k++] = b->GardnerDetectorVariables.delay3; s[k++] = b->GardnerDetectorVariables.delay4;
+    s[k++] = b->LoopFilterVariables.delay_x; s[k++] = b->LoopFilterVariables.delay_y;
+    s[k++] = b->PhaseCorrectionVariables.dds_delay;
+    s[k++] = b->PhaseLoopFilterVariables.delay_x; s[k++] = b->PhaseLoopFilterVariables.delay_y;
+    cc[0] = b->m_phase_ambiguity_cc_000.value();
+    cc[1] = b->m_phase_ambiguity_cc_090.value();
+    cc[2] = b->m_phase_ambiguity_cc_180.value();
+    cc[3] = b->m_phase_ambiguity_cc_270.value();
+}
+
+} // extern "C"

@@ -1,0 +1,602 @@
+/*
+ * sdr_oracle.c -- CPU restatement of the reference hot path (see sdr_oracle.h).
+ * TEST INFRASTRUCTURE ONLY: never linked into or called from the product.
+ *
+ * All arithmetic is IEEE fp64, one rounding per operation, in the reference's
+ * source order (the reference's unit-test build is -O0, RadioNode/CMakeLists.txt:8-10),
+ * so compile with -ffp-contract=off.
+ */
+#include "sdr_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/sdrx_math.h"
+
+static const double ORC_PI = 3.141592653589793238460; /* Common_Deffinitions.h:14 */
+#define SGN(v) (((v) == 0.0) ? 0.0 : (((v) < 0.0) ? -1.0 : 1.0)) /* BPSK.h:16 */
+
+/* ------------------------------------------------------------------ Filter */
+
+int orc_fir_design(int type, int two_freq, int num_taps, double Fs, double Fx, double Fu,
+                   int max_taps, double *taps)
+{
+    double lambda = M_PI * Fx / (Fs / 2); /* filt.cpp:52 / :82 */
+    if (!two_freq) {                      /* filt.cpp:45-70 */
+        if (Fs <= 0) return -1;
+        if (Fx <= 0 || Fx >= Fs / 2) return -2;
+        if (num_taps <= 0 || num_taps > max_taps) return -3;
+        if (type != ORC_LPF && type != ORC_HPF) return -5;
+        for (int n = 0; n < num_taps; n++) {
+            double mm = n - (num_taps - 1.0) / 2.0;
+            if (type == ORC_LPF) { /* filt.cpp:116-120 */
+                if (mm == 0.0) taps[n] = lambda / M_PI;
+                else taps[n] = sin(mm * lambda) / (mm * M_PI);
+            } else { /* filt.cpp:131-135 */
+                if (mm == 0.0) taps[n] = 1.0 - lambda / M_PI;
+                else taps[n] = -sin(mm * lambda) / (mm * M_PI);
+            }
+        }
+        return 0;
+    }
+    /* filt.cpp:73-102 */
+    double phi = M_PI * Fu / (Fs / 2);
+    if (Fs <= 0) return -10;
+    if (Fx >= Fu) return -11;
+    if (Fx <= 0 || Fx >= Fs / 2) return -12;
+    if (Fu <= 0 || Fu >= Fs / 2) return -13;
+    if (num_taps <= 0 || num_taps > max_taps) return -14;
+    if (type != ORC_BPF) return -16;
+    for (int n = 0; n < num_taps; n++) { /* filt.cpp:146-151 */
+        double mm = n - (num_taps - 1.0) / 2.0;
+        if (mm == 0.0) taps[n] = (phi - lambda) / M_PI;
+        else taps[n] = (sin(mm * phi) - sin(mm * lambda)) / (mm * M_PI);
+    }
+    return 0;
+}
+
+void orc_fir_execute(const double *taps, int T, double *sr, double *buf, size_t n)
+{
+    for (size_t s = 0; s < n; s++) { /* filt.cpp:267-273 */
+        for (int i = T - 1; i >= 1; i--) sr[i] = sr[i - 1]; /* filt.cpp:256-258 */
+        sr[0] = buf[s];
+        double result = 0;
+        for (int i = 0; i < T; i++) result += sr[i] * taps[i]; /* filt.cpp:262 */
+        buf[s] = result;
+    }
+}
+
+void orc_fir_execute_fast(const double *taps, int T, double *hist, double *buf, size_t n)
+{
+    /* x laid out oldest..newest: [x[-(T-1)] .. x[-1] | x[0] .. x[n-1]] */
+    size_t H = (size_t)(T - 1);
+    double *x = (double *)malloc((H + n) * sizeof(double));
+    for (size_t k = 0; k < H; k++) x[H - 1 - k] = hist[k];
+    memcpy(x + H, buf, n * sizeof(double));
+    for (size_t s = 0; s < n; s++) {
+        const double *p = x + H + s;
+        double result = 0;
+        for (int i = 0; i < T; i++) result += p[-i] * taps[i];
+        buf[s] = result;
+    }
+    for (size_t k = 0; k < H; k++) hist[k] = x[H + n - 1 - k];
+    free(x);
+}
+
+/* ---------------------------------------------------------------------- AM */
+
+size_t orc_raw_upsample(const double *in, size_t in_len, double *out, size_t out_len, double ratio)
+{
+    for (size_t oi = 0, ii = 0; oi < out_len && ii < in_len; ii++) /* Resample.h:18-24 */
+        for (int j = 0; (j < floor(ratio)) && (oi < out_len); j++) out[oi++] = in[ii];
+    return out_len;
+}
+
+void orc_am_modulate(const uint8_t *bits, size_t len, double *out_real, size_t len_mod)
+{
+    double *tmp = (double *)malloc((len ? len : 1) * sizeof(double)); /* AM.h:43-48 */
+    for (size_t i = 0; i < len; i++) tmp[i] = bits[i];
+    orc_raw_upsample(tmp, len, out_real, len_mod, (double)len_mod / (double)len); /* AM.h:51 */
+    free(tmp);
+}
+
+size_t orc_am_demodulate(const double *re, const double *im, uint8_t *out, size_t n, size_t ds)
+{
+    size_t oi = 0;
+    for (size_t i = 0; i < n; i += ds, oi++) /* AM.h:68-74 */
+        out[oi] = ((sqrt(re[i] * re[i] + im[i] * im[i]) >= 80.0) ? 1.0 : 0.0);
+    return oi;
+}
+
+int32_t orc_ones_zeros(const double *re, const double *im, size_t n)
+{
+    int32_t ones = 0;
+    for (size_t i = 0; i < n; i++) /* rtlsdr_receiver.cpp:2063-2074 */
+        if (sqrt(re[i] * re[i] + im[i] * im[i]) >= 80.0) ones++;
+    return ones;
+}
+
+/* ---------------------------------------------------------------------- FM */
+
+void orc_fm_modulate(double tx_rate, double mark, double space, const uint8_t *bits, size_t len,
+                     double *out_real, size_t spb)
+{
+    const double delta_t = 1.0 / tx_rate; /* FM.h:46-47 */
+    const double root_raised = sqrt(2) / sqrt(spb);
+    double *w1 = (double *)malloc((spb ? spb : 1) * sizeof(double));
+    double *w2 = (double *)malloc((spb ? spb : 1) * sizeof(double));
+    for (size_t i = 0; i < spb; i++) { /* FM.h:53-57 */
+        w1[i] = root_raised * cos(2.0 * ORC_PI * mark * delta_t * i);
+        w2[i] = root_raised * cos(2.0 * ORC_PI * space * delta_t * i);
+    }
+    for (size_t i = 0; i < len; i++) /* FM.h:59-70 */
+        memcpy(&out_real[i * spb], bits[i] == 0 ? w2 : w1, spb * sizeof(double));
+    free(w1);
+    free(w2);
+}
+
+void orc_fm_waves(double rx_rate, double mark, double space, size_t ds, double *w1, double *w2)
+{
+    const double delta_t = 1.0 / rx_rate; /* FM.h:125 */
+    for (size_t i = 0; i < ds; i++) {     /* FM.h:127-131 */
+        w1[i] = sqrt(2.0 / ds) * cos(2.0 * ORC_PI * mark * i * delta_t);
+        w2[i] = sqrt(2.0 / ds) * cos(2.0 * ORC_PI * space * i * delta_t);
+    }
+}
+
+size_t orc_fm_demodulate(double rx_rate, double mark, double space, const double *re, uint8_t *out,
+                         size_t n, size_t ds)
+{
+    size_t length = n / ds; /* FM.h:114 */
+    double *w1 = (double *)malloc((ds ? ds : 1) * sizeof(double));
+    double *w2 = (double *)malloc((ds ? ds : 1) * sizeof(double));
+    orc_fm_waves(rx_rate, mark, space, ds, w1, w2);
+    /* FM.h:94-100 with the 7th parameter ds restored: window [b*ds, b*ds+ds-1],
+     * accumulated last sample first, accumulator starting at 0 */
+    size_t b = 0;
+    for (size_t i = ds - 1; i < n; i += ds, b++) {
+        double op1 = 0, op2 = 0;
+        for (size_t j = 0; j < ds; j++) op1 += re[i - j] * w1[ds - j - 1];
+        for (size_t j = 0; j < ds; j++) op2 += re[i - j] * w2[ds - j - 1];
+        out[b] = (op1 > op2) ? 1 : 0; /* FM.h:139 repaired */
+    }
+    free(w1);
+    free(w2);
+    return length;
+}
+
+/* ----------------------------------------------------------- discriminator */
+
+static double orc_atan2(double y, double x, int math_mode)
+{
+    return math_mode == ORC_MATH_SHARED ? sdrx_atan2(y, x) : atan2(y, x);
+}
+
+void orc_fm_discriminator(const double *re, const double *im, size_t n, double *pre, double *out,
+                          int math_mode)
+{
+    double pr = pre[0], pj = pre[1];
+    for (size_t i = 0; i < n; i++) {
+        double ar = re[i], aj = im[i], br = pr, bj = -pj; /* rtl_fm.c:432 multiply(a, conj b) */
+        double cr = ar * br - aj * bj;                    /* rtl_fm.c:424 */
+        double cj = aj * br + ar * bj;                    /* rtl_fm.c:425 */
+        out[i] = orc_atan2(cj, cr, math_mode);            /* rtl_fm.c:433 */
+        pr = ar;
+        pj = aj;
+    }
+    pre[0] = pr; /* rtl_fm.c:543-544 */
+    pre[1] = pj;
+}
+
+void orc_fm_discriminator_i16(const int16_t *iq, size_t n, int16_t *pre, int16_t *out, int math_mode)
+{
+    int pr = pre[0], pj = pre[1];
+    for (size_t i = 0; i < n; i++) {
+        int ar = iq[2 * i], aj = iq[2 * i + 1], br = pr, bj = -pj;
+        int cr = ar * br - aj * bj;
+        int cj = aj * br + ar * bj;
+        double angle = orc_atan2((double)cj, (double)cr, math_mode);
+        out[i] = (int16_t)(int)(angle / 3.14159 * (1 << 14)); /* rtl_fm.c:434 */
+        pr = ar;
+        pj = aj;
+    }
+    pre[0] = (int16_t)pr;
+    pre[1] = (int16_t)pj;
+}
+
+/* ---------------------------------------------------------------- Resample */
+
+size_t orc_decimate(double *block, size_t length, size_t by)
+{
+    size_t dst = 0, src = 0;
+    while (src < length) { /* Resample.h:39-44 */
+        block[dst] = block[src];
+        src += by;
+        dst++;
+    }
+    for (size_t j = dst; j < length; j++) block[dst] = 0; /* Resample.h:46-49 (sic: index dst) */
+    return dst;
+}
+
+size_t orc_upsample_fill_w_zeros(const double *in, size_t in_len, double *out, size_t out_len, double ratio)
+{
+    for (size_t oi = 0, ii = 0; oi < out_len && ii < in_len; ii++) { /* Resample.cpp:26-33 */
+        out[oi++] = in[ii];
+        for (int j = 0; j < (ceil(ratio) - 1) && oi < out_len && ii < in_len; j++) out[oi++] = 0;
+    }
+    return out_len;
+}
+
+/* ------------------------------------------------------------------ chains */
+
+size_t orc_chain_fir_am(const double *taps, int T, double *histI, double *histQ, const double *re,
+                        const double *im, size_t n, size_t ds, uint8_t *bits)
+{
+    double *fi = (double *)malloc((n ? n : 1) * sizeof(double));
+    double *fq = (double *)malloc((n ? n : 1) * sizeof(double));
+    memcpy(fi, re, n * sizeof(double));
+    memcpy(fq, im, n * sizeof(double));
+    orc_fir_execute_fast(taps, T, histI, fi, n);
+    orc_fir_execute_fast(taps, T, histQ, fq, n);
+    size_t r = orc_am_demodulate(fi, fq, bits, n, ds);
+    free(fi);
+    free(fq);
+    return r;
+}
+
+size_t orc_chain_fir_decim_disc(const double *taps, int T, double *histI, double *histQ, double *pre,
+                                const double *re, const double *im, size_t n, size_t D, double *out,
+                                int math_mode)
+{
+    double *fi = (double *)malloc((n ? n : 1) * sizeof(double));
+    double *fq = (double *)malloc((n ? n : 1) * sizeof(double));
+    memcpy(fi, re, n * sizeof(double));
+    memcpy(fq, im, n * sizeof(double));
+    orc_fir_execute_fast(taps, T, histI, fi, n);
+    orc_fir_execute_fast(taps, T, histQ, fq, n);
+    size_t m = orc_decimate(fi, n, D);
+    (void)orc_decimate(fq, n, D);
+    orc_fm_discriminator(fi, fq, m, pre, out, math_mode);
+    free(fi);
+    free(fq);
+    return m;
+}
+
+/* --------------------------------------------------------------------- PSK */
+
+const double ORC_RRC[129] = { /* MATLAB rcosine(1/8,1,'sqrt',0.5,8): BPSK.cpp:18-50 */
+    -0.000882663055055987, -0.000746201590523265, -0.000336789968798916, 0.000225038893553655,
+    0.000757880681389978,  0.001077943504359050,  0.001062303725777150,  0.000695521249813576,
+    8.24465490986367e-05,  -0.000579554041955506, -0.001062303725777150, -0.001183702054816000,
+    -0.000874477709296126, -0.000211083163638599, 0.000599193283619645,  0.001279536876191750,
+    0.001573979573701230,  0.001338143762729140,  0.000599193283619642,  -0.000438236415412023,
+    -0.001446863119017230, -0.002078893324143190, -0.002084671221261930, -0.001408617284422990,
+    -0.000227352605090172, 0.001088699270085450,  0.002084671221261940,  0.002371289907799650,
+    0.001768388256576610,  0.000391988582678128,  -0.001351122110122730, -0.002869993360503870,
+    -0.003572683794274230, -0.003072685906611650, -0.001351122110122720, 0.001186107048403510,
+    0.003789403406949890,  0.005575980755162950,  0.005816670050933640,  0.004213278581633850,
+    0.001071805138282270,  -0.002702696087965530, -0.005816670050933650, -0.006968745846090550,
+    -0.005305164769729840, -0.000815536975401244, 0.005468827588591990,  0.011573823048484000,
+    0.015005271935951800,  0.013430574641186900,  0.005468827588591980,  -0.008615615450369140,
+    -0.026525823848649200, -0.044008760276746200, -0.055452254485567400, -0.054931750238658300,
+    -0.037513179839879400, -0.000532386899804849, 0.055452254485567400,  0.126288206185736000,
+    0.204577471545948000,  0.280728910881642000,  0.344536138081295000,  0.386975375596443000,
+    0.401855774335913000,  0.386975375596443000,  0.344536138081295000,  0.280728910881642000,
+    0.204577471545948000,  0.126288206185736000,  0.055452254485567400,  -0.000532386899804849,
+    -0.037513179839879400, -0.054931750238658300, -0.055452254485567400, -0.044008760276746200,
+    -0.026525823848649200, -0.008615615450369140, 0.005468827588591980,  0.013430574641186900,
+    0.015005271935951800,  0.011573823048484000,  0.005468827588591990,  -0.000815536975401244,
+    -0.005305164769729840, -0.006968745846090550, -0.005816670050933650, -0.002702696087965530,
+    0.001071805138282270,  0.004213278581633850,  0.005816670050933640,  0.005575980755162950,
+    0.003789403406949890,  0.001186107048403510,  -0.001351122110122720, -0.003072685906611650,
+    -0.003572683794274230, -0.002869993360503870, -0.001351122110122730, 0.000391988582678128,
+    0.001768388256576610,  0.002371289907799650,  0.002084671221261940,  0.001088699270085450,
+    -0.000227352605090172, -0.001408617284422990, -0.002084671221261930, -0.002078893324143190,
+    -0.001446863119017230, -0.000438236415412023, 0.000599193283619642,  0.001338143762729140,
+    0.001573979573701230,  0.001279536876191750,  0.000599193283619645,  -0.000211083163638599,
+    -0.000874477709296126, -0.001183702054816000, -0.001062303725777150, -0.000579554041955506,
+    8.24465490986367e-05,  0.000695521249813576,  0.001062303725777150,  0.001077943504359050,
+    0.000757880681389978,  0.000225038893553655,  -0.000336789968798916, -0.000746201590523265,
+    -0.000882663055055987};
+
+static const double QPSK_DEFAULT_UW[64] = { /* QPSK.cpp:20-28 */
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 2, 1, 0, 3, 2, 1, 2, 0, 1, 2, 3, 2, 2, 3};
+static const double LUT_B_REAL[2] = {1, -1};        /* BPSK.cpp:14 */
+static const double LUT_B_180[2] = {1, 0};          /* BPSK.cpp:15 */
+static const double LUT_Q_REAL[4] = {1, -1, 1, -1}; /* QPSK.cpp:14 */
+static const double LUT_Q_IMAG[4] = {1, 1, -1, -1}; /* QPSK.cpp:15 */
+static const double LUT_Q_000[4] = {0, 1, 2, 3};    /* QPSK.cpp:16 */
+static const double LUT_Q_090[4] = {2, 0, 3, 1};    /* QPSK.cpp:17 */
+static const double LUT_Q_180[4] = {3, 2, 1, 0};    /* QPSK.cpp:18 */
+static const double LUT_Q_270[4] = {1, 3, 0, 2};    /* QPSK.cpp:19 */
+
+static void psk_common_init(orc_psk *s, int kind, size_t uw_len, int math_mode)
+{
+    memset(s, 0, sizeof(*s));
+    s->g1 = s->g2 = s->g3 = s->g4 = 1; /* BPSK.cpp:68-71 */
+    for (int i = 0; i < 4; i++) s->cc[i] = 10 / 2; /* confidence_counter.cpp:7 */
+    s->kind = kind;
+    s->uw_size = (int32_t)uw_len;
+    s->math_mode = math_mode;
+}
+
+void orc_bpsk_init(orc_psk *s, uint64_t unique_word, size_t uw_len, int math_mode)
+{
+    psk_common_init(s, ORC_BPSK, uw_len, math_mode);
+    if (uw_len > 64) return; /* BPSK.cpp:79 */
+    for (int i = (int)uw_len - 1; i >= 0; i--) { /* BPSK.cpp:83-89 */
+        uint64_t mask = 1ULL << i;
+        s->uw[0][i] = ((unique_word & mask) > 0) ? 1 : 0;
+        s->uw[1][i] = ((unique_word & mask) > 0) ? 0 : 1;
+    }
+}
+
+void orc_qpsk_init(orc_psk *s, const double *uw, size_t uw_len, int math_mode)
+{
+    psk_common_init(s, ORC_QPSK, uw_len, math_mode);
+    if (!uw) uw = QPSK_DEFAULT_UW;
+    if (uw_len > 64) return;                               /* QPSK.cpp:96 */
+    for (int i = 64 - 1; i >= 64 - (int)uw_len && i >= 0; i--) { /* QPSK.cpp:102-118 */
+        if (uw[i] >= 0 && uw[i] <= 3) {
+            s->uw[0][i] = LUT_Q_000[(int)uw[i]];
+            s->uw[1][i] = LUT_Q_270[(int)uw[i]]; /* uw_090 <- LUT_REAL_270 (QPSK.cpp:107) */
+            s->uw[2][i] = LUT_Q_180[(int)uw[i]];
+            s->uw[3][i] = LUT_Q_090[(int)uw[i]]; /* uw_270 <- LUT_REAL__90 (QPSK.cpp:109) */
+        }
+    }
+}
+
+void orc_psk_encode_lut(int kind, const uint8_t *data, size_t len, double *re, double *im)
+{
+    for (size_t i = 0; i < len; i++) {
+        if (kind == ORC_BPSK) re[i] = LUT_B_REAL[data[i]]; /* BPSK.cpp:116-119 */
+        else {
+            re[i] = LUT_Q_REAL[data[i]]; /* QPSK.cpp:148-152 */
+            im[i] = LUT_Q_IMAG[data[i]];
+        }
+    }
+}
+
+void orc_psk_pulse_shape(const double *sym, size_t len, double *out, size_t zero_prefix)
+{
+    size_t n = len * 8;
+    double *data = (double *)calloc(n + 129 * 2, sizeof(double)); /* BPSK.cpp:132-133 */
+    orc_upsample_fill_w_zeros(sym, len, &data[129], n, 8);       /* BPSK.cpp:135 */
+    for (size_t i = 0; i < n && i < zero_prefix; i++) out[i] = 0; /* BPSK.cpp:131 (bytes, not doubles) */
+    for (size_t i = 0; i < n; i++)                                /* BPSK.cpp:137-143 */
+        for (int j = 0; j < 129; j++) out[i] += data[i + 129 - j] * ORC_RRC[129 - j - 1];
+    free(data);
+}
+
+size_t orc_psk_decode_pulse_shape(const double *iq, size_t n, double *re, double *im)
+{
+    double *rd = (double *)calloc(n + 129 * 2, sizeof(double)); /* BPSK.cpp:262-270 */
+    double *id = (double *)calloc(n + 129 * 2, sizeof(double));
+    double *ri = (double *)calloc(n ? n : 1, sizeof(double));
+    double *ii = (double *)calloc(n ? n : 1, sizeof(double));
+    for (size_t i = 0; i < n; i++) { /* BPSK.cpp:273-277 */
+        rd[i + 129] = iq[2 * i];
+        id[i + 129] = iq[2 * i + 1];
+    }
+    for (size_t i = 0; i < n; i++) /* BPSK.cpp:279-286 */
+        for (int j = 0; j < 129; j++) {
+            ri[i] += rd[i + 129 - j] * ORC_RRC[129 - j - 1];
+            ii[i] += id[i + 129 - j] * ORC_RRC[129 - j - 1];
+        }
+    (void)orc_decimate(ri, n, 4); /* BPSK.cpp:289-290 */
+    (void)orc_decimate(ii, n, 4);
+    memcpy(re, ri, sizeof(double) * (n / 4)); /* BPSK.cpp:292-293 */
+    memcpy(im, ii, sizeof(double) * (n / 4));
+    free(rd);
+    free(id);
+    free(ri);
+    free(ii);
+    return n / 4;
+}
+
+static double interp_filter(orc_interp *d, double in, double mu)
+{
+    const double K = -0.5; /* BPSK.cpp:319-344 */
+    double V1 = d->d1 - K * in;
+    double V2 = V1 + d->d2;
+    double V3 = V2 - d->d3;
+    double V4 = K * in - d->d1 + d->d4;
+    double V5 = V4 + d->d2;
+    double V6 = d->d3 + V5;
+    double V7 = V3 * mu + V6;
+    double V8 = d->d5 + mu * V7;
+    d->d3 = d->d2;
+    d->d2 = d->d1;
+    d->d1 = K * in;
+    d->d5 = d->d4;
+    d->d4 = in;
+    return V8;
+}
+
+static double strobe_reg(double input, double strobe, double *reg)
+{
+    if (strobe >= 1) *reg = input; /* BPSK.cpp:382-389 */
+    return *reg;
+}
+
+void orc_psk_timing(orc_psk *s, double *re, double *im, size_t n)
+{
+    for (size_t i = 0; i < n; i++) { /* BPSK.cpp:307-316 */
+        double strobe = (s->nco_delay < 0) ? 1 : 0;
+        double mu = strobe_reg(s->mu_delay * 2, strobe, &s->reg_mu);
+        double Q = interp_filter(&s->interp_q, re[i], mu); /* "Q" gets real (sic) */
+        double I = interp_filter(&s->interp_i, im[i], mu);
+        /* GardnerDetector, BPSK.cpp:346-363 */
+        double e = 0;
+        if (strobe >= 0.5)
+            e = (s->g3 * (-SGN(Q) + SGN(s->g4)) + (s->g1 * (-SGN(I) + SGN(s->g2))));
+        s->g2 = s->g1;
+        s->g1 = I;
+        s->g4 = s->g3;
+        s->g3 = Q;
+        /* LoopFilter, BPSK.cpp:365-373 */
+        const double K1 = -0.00587880145347487, K2 = -2.35152058138995e-05;
+        double v = s->lf_y + K2 * e + K1 * (e - s->lf_x);
+        s->lf_x = e;
+        s->lf_y = v;
+        /* NcoControl, BPSK.cpp:375-380 */
+        double eta = s->nco_delay - floor(s->nco_delay);
+        s->nco_delay = eta - 0.5 - v;
+        s->mu_delay = eta;
+        re[i] = strobe_reg(Q, strobe, &s->reg_Q);
+        im[i] = strobe_reg(I, strobe, &s->reg_I);
+    }
+}
+
+static double phase_loop_filter(orc_psk *s, double val)
+{
+    const double K1 = 0.0620001240002480, K2 = 0.000992001984003968; /* BPSK.cpp:424-432 */
+    double r = s->plf_y - K1 * s->plf_x + (K1 + K2) * val;
+    s->plf_x = val;
+    s->plf_y = r;
+    return r;
+}
+
+static void dds(orc_psk *s, double arg, double *c, double *sn)
+{
+    if (s->math_mode == ORC_MATH_SHARED) sdrx_sincos(arg, sn, c);
+    else {
+        *c = cos(arg);
+        *sn = sin(arg);
+    }
+}
+
+size_t orc_psk_phase_correction(orc_psk *s, double *re, double *im, size_t n)
+{
+    double tr = 0, ti = 0, temp = 0;
+    const double constant = 8.0;
+    for (size_t i = 0; i < n; i++) {
+        double c, sn;
+        if (s->kind == ORC_BPSK) { /* BPSK.cpp:399-411 */
+            dds(s, s->dds_delay + temp, &c, &sn);
+            s->dds_delay = s->dds_delay + temp;
+            tr = re[i] * c - im[i] * sn; /* BPSK.cpp:417-421 */
+            ti = im[i] * c + re[i] * sn;
+            temp = phase_loop_filter(s, constant * (SGN(ti) * tr - SGN(tr) * ti));
+            re[i] = (SGN(tr) < 0) ? 1 : 0; /* BPSK.cpp:434-444 */
+        } else {                           /* QPSK.cpp:361-373 */
+            temp = phase_loop_filter(s, constant * (SGN(ti) * tr - SGN(tr) * ti));
+            dds(s, s->dds_delay + temp, &c, &sn);
+            s->dds_delay = s->dds_delay + temp;
+            tr = re[i] * c - im[i] * sn;
+            ti = im[i] * c + re[i] * sn;
+            double sr = SGN(tr), si = SGN(ti); /* QPSK.cpp:396-414 */
+            if (sr < 0 && si < 0) re[i] = 3;
+            else if (sr > 0 && si < 0) re[i] = 2;
+            else if (sr < 0 && si > 0) re[i] = 1;
+            else re[i] = 0;
+        }
+        im[i] = 0;
+    }
+    return orc_decimate(re, n, 2); /* BPSK.cpp:413 */
+}
+
+static void cc_inc(int32_t *c) /* confidence_counter.cpp:41-50, max 10 */
+{
+    (*c)++;
+    if (*c >= 10) *c = 10;
+}
+static void cc_dec(int32_t *c) /* confidence_counter.cpp:52-61 */
+{
+    (*c)--;
+    if (*c <= 0) *c = 0;
+}
+#define CC_HIGH(c) ((c) >= 5) /* confidence_counter.cpp:23-30, high_threshold 5 */
+
+size_t orc_psk_ambiguity(orc_psk *s, double *re, size_t n, uint64_t *events, size_t max_events)
+{
+    size_t U = (size_t)s->uw_size, hits = 0;
+    if (s->kind == ORC_BPSK) {
+        for (size_t i = 0; n >= U && i < n - U; i++) { /* BPSK.cpp:449-476 */
+            size_t m0 = 0, m180 = 0;
+            for (size_t j = 0; j < U; j++) {
+                if (re[i + j] == s->uw[0][U - 1 - j]) m0++;
+                if (re[i + j] == s->uw[1][U - 1 - j]) m180++;
+            }
+            int code = -1;
+            if (m0 == U) { cc_dec(&s->cc[0]); code = 0; }
+            else if (m180 == U) { cc_inc(&s->cc[0]); code = 2; }
+            if (code >= 0) {
+                if (events && hits < max_events) events[hits] = ((uint64_t)i << 3) | (uint64_t)code;
+                hits++;
+            }
+        }
+        if (CC_HIGH(s->cc[0])) /* BPSK.cpp:478-485 */
+            for (size_t i = 0; i < n; i++) re[i] = LUT_B_180[(int)re[i]];
+        return hits;
+    }
+    for (size_t i = 0; n >= U && i < n - U; i++) { /* QPSK.cpp:419-478 */
+        size_t m[4] = {0, 0, 0, 0};
+        for (size_t j = 0; j < U; j++) {
+            double v = re[i + j];
+            if (v == s->uw[0][63 - j]) m[0]++;
+            else if (v == s->uw[1][63 - j]) m[1]++;
+            else if (v == s->uw[2][63 - j]) m[2]++;
+            else if (v == s->uw[3][63 - j]) m[3]++;
+        }
+        int code = -1;
+        for (int k = 0; k < 4; k++)
+            if (m[k] == U) { code = k; break; }
+        if (code >= 0) {
+            for (int k = 0; k < 4; k++) {
+                if (k == code) cc_inc(&s->cc[k]);
+                else cc_dec(&s->cc[k]);
+            }
+            if (events && hits < max_events) events[hits] = ((uint64_t)i << 3) | (uint64_t)code;
+            hits++;
+        }
+    }
+    const double *lut = NULL; /* QPSK.cpp:481-507 */
+    if (CC_HIGH(s->cc[1])) lut = LUT_Q_090;
+    else if (CC_HIGH(s->cc[2])) lut = LUT_Q_180;
+    else if (CC_HIGH(s->cc[3])) lut = LUT_Q_270;
+    if (lut)
+        for (size_t i = 0; i < n; i++) re[i] = lut[(int)re[i]];
+    return hits;
+}
+
+size_t orc_psk_demodulate(orc_psk *s, const double *iq, size_t n, double *out, double *timing_re,
+                          double *timing_im)
+{
+    size_t cap = n ? n : 1;
+    double *re = (double *)calloc(cap, sizeof(double)); /* BPSK.cpp:150-154 */
+    double *im = (double *)calloc(cap, sizeof(double));
+    size_t m = orc_psk_decode_pulse_shape(iq, n, re, im); /* BPSK.cpp:157 */
+    orc_psk_timing(s, re, im, m);                         /* BPSK.cpp:159 */
+    if (timing_re) memcpy(timing_re, re, m * sizeof(double));
+    if (timing_im) memcpy(timing_im, im, m * sizeof(double));
+    m = orc_psk_phase_correction(s, re, im, m); /* BPSK.cpp:161 */
+    orc_psk_ambiguity(s, re, m, NULL, 0);       /* BPSK.cpp:163 */
+    memcpy(out, re, m * sizeof(double));        /* BPSK.cpp:167-172 */
+    free(re);
+    free(im);
+    return m;
+}
+
+void orc_bpsk_modulate(const uint8_t *bits, size_t len, double *out_real, size_t len_mod)
+{
+    if (len_mod < 8 * len) return; /* BPSK.cpp:125-129 */
+    double *sym = (double *)calloc(len * 8 + 1, sizeof(double));
+    orc_psk_encode_lut(ORC_BPSK, bits, len, sym, NULL);
+    orc_psk_pulse_shape(sym, len, out_real, len_mod / 8);
+    free(sym);
+}
+
+void orc_qpsk_modulate(const uint8_t *symb, size_t len, double *out_real, double *out_imag, size_t len_mod)
+{
+    if (len_mod != 8 * len) return; /* QPSK.cpp:158-162 */
+    double *sr = (double *)calloc(len * 8 + 1, sizeof(double));
+    double *si = (double *)calloc(len * 8 + 1, sizeof(double));
+    orc_psk_encode_lut(ORC_QPSK, symb, len, sr, si);
+    orc_psk_pulse_shape(sr, len, out_real, len_mod / 8);
+    orc_psk_pulse_shape(si, len, out_imag, len_mod / 8);
+    free(sr);
+    free(si);
+}

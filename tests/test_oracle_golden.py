@@ -1,0 +1,329 @@
+"""Pin the CPU restatement (oracle/) against every golden vector the reference's own unit
+tests hold for the path.  Each test mirrors one reference TEST (file:line in the docstring)
+with the reference's own tolerance.  CPU only.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+L = O.lib()
+
+
+def G(golden, key):
+    return np.array(golden[key])
+
+
+# ----------------------------------------------------------------------------- AM / Resample
+
+def test_am_modulate(golden):
+    """TEST(AM, modulate) TEST_AM.cpp:14-35: 1000 bits -> 8000 samples, exact."""
+    bits = G(golden, "TEST_AM__AM__modulate__inputStream")
+    want = G(golden, "TEST_AM__AM__modulate__modulatedStream")
+    got = O.am_modulate(bits, 8000)
+    assert np.array_equal(got, want)
+
+
+def test_am_demodulate(golden):
+    """TEST(AM, demodulate) TEST_AM.cpp:38-58: amplitude x127, ds=8, exact bits."""
+    x = G(golden, "TEST_AM__AM__demodulate__modulatedStream") * 127.0
+    want = G(golden, "TEST_AM__AM__demodulate__ouputStream")
+    got = O.am_demodulate(x, x, 8)
+    assert np.array_equal(got[:1000], want)
+
+
+def test_am_moddemod(golden):
+    """TEST(AM, ModDemod) TEST_Modulator_Demodulator.cpp:123-162."""
+    bits = G(golden, "TEST_Modulator_Demodulator__AM__ModDemod__inputStream")
+    mod = O.am_modulate(bits, 8000)
+    assert np.array_equal(mod, G(golden, "TEST_Modulator_Demodulator__AM__ModDemod__modulatedStream"))
+    mod *= 127.0
+    got = O.am_demodulate(mod, mod, 8)
+    assert np.array_equal(got[:1000], G(golden, "TEST_Modulator_Demodulator__AM__ModDemod__ouputStream"))
+
+
+def test_upsample_fill_w_zeros(golden):
+    """TEST(Resample, upsample_with) TEST_Resample.cpp:8-28."""
+    msg = G(golden, "TEST_Resample__Resample__upsample_with__message")
+    out = np.zeros(64)
+    L.orc_upsample_fill_w_zeros(msg, 8, out, 64, 8.0)
+    assert np.array_equal(out, G(golden, "TEST_Resample__Resample__upsample_with__final_message"))
+
+
+# ----------------------------------------------------------------------------- FM
+
+def test_fm_modulate(golden):
+    """TEST(FM, modulate) TEST_FM.cpp:14-37: FM(100,10,20,10), spb 100, 1e-9."""
+    bits = G(golden, "TEST_FM__FM__modulate__inputStream")
+    want = G(golden, "TEST_FM__FM__modulate__modulatedStream")
+    got = O.fm_modulate(100.0, 20.0, 10.0, bits, 100)
+    assert np.allclose(got, want, rtol=0, atol=1e-9)
+
+
+def test_fm_demodulate(golden):
+    """TEST(FM, demodulate) TEST_FM.cpp:40-59: FM(100,100,20,10).demodulate(.., 1000, 100) -> 10 bits."""
+    x = G(golden, "TEST_FM__FM__demodulate__modulatedRealStream")
+    want = G(golden, "TEST_FM__FM__demodulate__outputStream")
+    got = O.fm_demodulate(100.0, 20.0, 10.0, x, 100)
+    assert got.size == 10
+    assert np.array_equal(got, want)
+
+
+def test_fm_moddemod_resampled(golden):
+    """TEST(FM, ModDemodResampled) TEST_FM.cpp:61-99: FM(100,50,20,10), /2 decimated, ds=50."""
+    bits = G(golden, "TEST_FM__FM__ModDemodResampled__inputStream")
+    stream = G(golden, "TEST_FM__FM__ModDemodResampled__modulatedStream")
+    mod = O.fm_modulate(100.0, 20.0, 10.0, bits, 100)
+    assert np.allclose(mod, stream, rtol=0, atol=1e-9)
+    dec = stream.copy()
+    assert L.orc_decimate(dec, 1000, 2) == 500
+    got = O.fm_demodulate(50.0, 20.0, 10.0, dec[:500].copy(), 50)
+    assert got.size == 10
+    assert np.array_equal(got, G(golden, "TEST_FM__FM__ModDemodResampled__outputStream"))
+    assert np.array_equal(got, bits)
+
+
+# ----------------------------------------------------------------------------- BPSK stages
+
+def test_bpsk_encode_lut(golden):
+    """TEST(BPSK, encode_LUT) TEST_BPSK.cpp:18-36."""
+    data = G(golden, "TEST_BPSK______BPSK_DataToBeDifferentiallyEncoded")[:1250]
+    want = G(golden, "TEST_BPSK__BPSK__encode_LUT__encoded_data")[:1250]
+    re = np.zeros(1250)
+    L.orc_psk_encode_lut(O.BPSK, data, 1250, re, None)
+    assert np.array_equal(re, want)
+
+
+def test_bpsk_encode_pulse_shape(golden):
+    """TEST(BPSK, encode_pulseShape) TEST_BPSK.cpp:38-83: 10 symbols -> 80 samples @1e-8."""
+    sym = G(golden, "TEST_BPSK__BPSK__encode_pulseShape__Q_Channel")
+    want = G(golden, "TEST_BPSK__BPSK__encode_pulseShape__pulseShaped")
+    out = np.zeros(80)
+    L.orc_psk_pulse_shape(sym, 10, out, 80 // 8)
+    assert np.allclose(out, want, rtol=0, atol=1e-8)
+
+
+def test_bpsk_decode_pulse_shape(golden):
+    """TEST(BPSK, decode_pulseShape) TEST_BPSK.cpp:85-110: 800 -> 200 (198 checked) @1e-5."""
+    ps = G(golden, "TEST_BPSK__BPSK__decode_pulseShape__pulseShaped")[:800]
+    want = G(golden, "TEST_BPSK__BPSK__decode_pulseShape__RxCorrelated")
+    iq = np.zeros(1600)
+    iq[0::2] = ps
+    re, im = np.zeros(200), np.zeros(200)
+    assert L.orc_psk_decode_pulse_shape(iq, 800, re, im) == 200
+    assert np.allclose(re[:198], want[:198], rtol=0, atol=1e-5)
+    assert np.all(im == 0)
+
+
+def _interp(st_interp, x, mu):
+    """One InterpolationFilter step via the timing-loop internals is private; restate here (BPSK.cpp:319-344)."""
+    K = -0.5
+    d = st_interp
+    V1 = d["d1"] - K * x
+    V2 = V1 + d["d2"]
+    V3 = V2 - d["d3"]
+    V4 = K * x - d["d1"] + d["d4"]
+    V5 = V4 + d["d2"]
+    V6 = d["d3"] + V5
+    V7 = V3 * mu + V6
+    V8 = d["d5"] + mu * V7
+    d["d3"], d["d2"], d["d1"], d["d5"], d["d4"] = d["d2"], d["d1"], K * x, d["d4"], x
+    return V8
+
+
+def test_bpsk_timing_loop(golden):
+    """TEST(BPSK, symbol_timing_synchronization) TEST_BPSK.cpp:206-224: 1000 points @1e-8.
+    Pins InterpolationFilter, GardnerDetector, LoopFilter, NcoControl and StrobeEnabledRegister
+    together exactly as the reference's loop composes them."""
+    re = G(golden, "TEST_BPSK__BPSK__symbol_timing_synchronization__RxCorrelated_real")[:1000].copy()
+    im = G(golden, "TEST_BPSK__BPSK__symbol_timing_synchronization__RxCorrelated_imag")[:1000].copy()
+    st = O.psk_new(O.BPSK)
+    L.orc_psk_timing(C.byref(st), re, im, 1000)
+    wr = G(golden, "TEST_BPSK__BPSK__symbol_timing_synchronization__RxSymbolSynchronized_real")[:1000]
+    wi = G(golden, "TEST_BPSK__BPSK__symbol_timing_synchronization__RxSymbolSynchronized_imag")[:1000]
+    assert np.allclose(re, wr, rtol=0, atol=1e-8)
+    assert np.allclose(im, wi, rtol=0, atol=1e-8)
+
+
+def test_bpsk_interpolation_filter_vector(golden):
+    """TEST(BPSK, InterpolationFilter) TEST_BPSK.cpp:113-127: 200 points @1e-5 (stage formula)."""
+    IN = G(golden, "TEST_BPSK__BPSK__InterpolationFilter__IN")
+    MU = G(golden, "TEST_BPSK__BPSK__InterpolationFilter__MU")
+    OUT = G(golden, "TEST_BPSK__BPSK__InterpolationFilter__OUT")
+    d = dict(d1=0.0, d2=0.0, d3=0.0, d4=0.0, d5=0.0)
+    for i in range(200):
+        assert abs(OUT[i] - _interp(d, IN[i], MU[i])) < 1e-5
+
+
+def test_bpsk_phase_correction(golden):
+    """TEST(BPSK, rx_phase_correction) TEST_BPSK.cpp:367-383: 1000 -> 500 decisions (tol 0.1 == exact)."""
+    re = G(golden, "TEST_BPSK__BPSK__rx_phase_correction__RxCorrelated_real")[:1000].copy()
+    im = G(golden, "TEST_BPSK__BPSK__rx_phase_correction__RxCorrelated_imag")[:1000].copy()
+    want = G(golden, "TEST_BPSK__BPSK__rx_phase_correction__RxSymbolSynchronized_real")
+    for mode in (O.MATH_LIBM, O.MATH_SHARED):
+        r, i = re.copy(), im.copy()
+        st = O.psk_new(O.BPSK, math_mode=mode)
+        assert L.orc_psk_phase_correction(C.byref(st), r, i, 1000) == 500
+        assert np.array_equal(r[1:500], want[1:500])
+        assert np.all(i[:500] == 0)
+
+
+def test_bpsk_phase_ambiguity(golden):
+    """TEST(BPSK, phase_ambiguity_correction) TEST_BPSK.cpp:386-399: default BPSK(0x4E,8), 1000 bits."""
+    x = G(golden, "TEST_BPSK__BPSK__phase_ambiguity_correction__RX_PHASE_CORRECTED")[:1000].copy()
+    want = G(golden, "TEST_BPSK__BPSK__phase_ambiguity_correction__RX_PHASE_AMBIGUITY_DETECTED")
+    st = O.psk_new(O.BPSK)
+    L.orc_psk_ambiguity(C.byref(st), x, 1000, None, 0)
+    assert np.array_equal(x[529 + 8: 529 + 8 + 200], want[:200])
+
+
+def test_bpsk_full_moddemod(golden):
+    """TEST(BPSK, Full_ModDemod) TEST_Modulator_Demodulator.cpp:12-61: BPSK(0x14EB,16),
+    modulate 1000 bits (800 samples @1e-6), demodulate -> 990 bits exact."""
+    bits = G(golden, "TEST_Modulator_Demodulator__BPSK__Full_ModDemod__input_stream")
+    want_mod = G(golden, "TEST_Modulator_Demodulator__BPSK__Full_ModDemod__modulated_stream")
+    want_out = G(golden, "TEST_Modulator_Demodulator__BPSK__Full_ModDemod__output_stream")
+    assert bits.size == 1000
+    mod = np.zeros(8000)
+    L.orc_bpsk_modulate(bits, 1000, mod, 8000)
+    assert np.allclose(mod[:800], want_mod[:800], rtol=0, atol=1e-6)
+    iq = np.repeat(mod, 2)  # real == imag (TEST_Modulator_Demodulator.cpp:41-46)
+    for mode in (O.MATH_LIBM, O.MATH_SHARED):
+        st = O.psk_new(O.BPSK, 0x14EB, 16, math_mode=mode)
+        out = O.psk_demodulate(st, iq)
+        assert out.size == 1000
+        assert np.array_equal(out[:990], want_out[:990])
+
+
+# ----------------------------------------------------------------------------- QPSK stages
+
+def test_qpsk_encode_lut(golden):
+    """TEST(QPSK, encode_LUT) TEST_QPSK.cpp:12-36."""
+    data = G(golden, "TEST_QPSK__QPSK__encode_LUT__QPSK_DataToBeDifferentiallyEncoded")
+    re, im = np.zeros(100), np.zeros(100)
+    L.orc_psk_encode_lut(O.QPSK, data, 100, re, im.ctypes.data)
+    assert np.array_equal(re, G(golden, "TEST_QPSK__QPSK__encode_LUT__encoded_real_data"))
+    assert np.array_equal(im, G(golden, "TEST_QPSK__QPSK__encode_LUT__encoded_imag_data"))
+
+
+def test_qpsk_encode_pulse_shape(golden):
+    """TEST(QPSK, encode_pulseShape) TEST_QPSK.cpp:38-71: 1000 symbols -> 8000 @1e-8 on both rails."""
+    for ch in ("Q", "I"):
+        sym = G(golden, f"TEST_QPSK__QPSK__encode_pulseShape__{ch}_Channel")
+        want = G(golden, f"TEST_QPSK__QPSK__encode_pulseShape__pulseShaped_{ch}_Channel")
+        out = np.zeros(8000)
+        L.orc_psk_pulse_shape(sym, 1000, out, 1000)
+        assert np.allclose(out, want, rtol=0, atol=1e-8)
+
+
+def test_qpsk_decode_pulse_shape(golden):
+    """TEST(QPSK, decode_pulseShape) TEST_QPSK.cpp:74-108: 100 complex -> 25 (20 checked) @1e-8."""
+    iq = np.zeros(200)
+    iq[0::2] = G(golden, "TEST_QPSK__QPSK__decode_pulseShape__pulseShaped_Real")
+    iq[1::2] = G(golden, "TEST_QPSK__QPSK__decode_pulseShape__pulseShaped_Imag")
+    re, im = np.zeros(25), np.zeros(25)
+    assert L.orc_psk_decode_pulse_shape(iq, 100, re, im) == 25
+    assert np.allclose(re[:20], G(golden, "TEST_QPSK__QPSK__decode_pulseShape__RxCorrelated_Real"), rtol=0, atol=1e-8)
+    assert np.allclose(im[:20], G(golden, "TEST_QPSK__QPSK__decode_pulseShape__RxCorrelated_Imag"), rtol=0, atol=1e-8)
+
+
+def test_qpsk_timing_loop(golden):
+    """TEST(QPSK, symbol_timing_synchronization) TEST_QPSK.cpp:207-241: 2000 points @1e-5."""
+    re = G(golden, "TEST_QPSK__QPSK__symbol_timing_synchronization__RxCorrelated_real").copy()
+    im = G(golden, "TEST_QPSK__QPSK__symbol_timing_synchronization__RxCorrelated_imag").copy()
+    st = O.psk_new(O.QPSK)
+    L.orc_psk_timing(C.byref(st), re, im, 2000)
+    assert np.allclose(re, G(golden, "TEST_QPSK__QPSK__symbol_timing_synchronization__RxSymbolSynchronized_real"), rtol=0, atol=1e-5)
+    assert np.allclose(im, G(golden, "TEST_QPSK__QPSK__symbol_timing_synchronization__RxSymbolSynchronized_imag"), rtol=0, atol=1e-5)
+
+
+def test_qpsk_phase_correction(golden):
+    """TEST(QPSK, rx_phase_correction) TEST_QPSK.cpp:341-374: 1000 -> 500 symbols @1e-8 (exact)."""
+    re0 = G(golden, "TEST_QPSK__QPSK__rx_phase_correction__RxCorrelated_real")[:1000]
+    im0 = G(golden, "TEST_QPSK__QPSK__rx_phase_correction__RxCorrelated_imag")[:1000]
+    want = G(golden, "TEST_QPSK__QPSK__rx_phase_correction__RxSymbolSynchronized_real")
+    for mode in (O.MATH_LIBM, O.MATH_SHARED):
+        re, im = re0.copy(), im0.copy()
+        st = O.psk_new(O.QPSK, math_mode=mode)
+        assert L.orc_psk_phase_correction(C.byref(st), re, im, 1000) == 500
+        assert np.array_equal(re[1:500], want[1:500])
+
+
+def test_qpsk_phase_ambiguity(golden):
+    """TEST(QPSK, phase_ambiguity_correction) TEST_QPSK.cpp:376-407: 400 symbols, data from 161."""
+    x = G(golden, "TEST_QPSK__QPSK__phase_ambiguity_correction__RX_PHASE_CORRECTED")[:400].copy()
+    want = G(golden, "TEST_QPSK__QPSK__phase_ambiguity_correction__RX_PHASE_AMBIGUITY_DETECTED")
+    st = O.psk_new(O.QPSK)
+    L.orc_psk_ambiguity(C.byref(st), x, 400, None, 0)
+    assert np.array_equal(x[161:400], want[: 400 - 161])
+
+
+@pytest.mark.parametrize("src", ["TEST_QPSK__QPSK__Deconstructed_ModDemod", "TEST_Modulator_Demodulator__QPSK__Full_ModDemod"])
+def test_qpsk_deconstructed_and_full(golden, src):
+    """TEST(QPSK, Deconstructed_ModDemod) TEST_QPSK.cpp:409-507 and TEST(QPSK, Full_ModDemod)
+    TEST_Modulator_Demodulator.cpp:63-120: every stage pinned, then end to end."""
+    sym = G(golden, f"{src}__input_stream")
+    mr, mi = np.zeros(8000), np.zeros(8000)
+    L.orc_qpsk_modulate(sym, 1000, mr, mi, 8000)
+    assert np.allclose(mr, G(golden, f"{src}__real_modulated_stream"), rtol=0, atol=1e-8)
+    assert np.allclose(mi, G(golden, f"{src}__imag_modulated_stream"), rtol=0, atol=1e-8)
+    iq = np.empty(16000)
+    iq[0::2], iq[1::2] = mr, mi
+    for mode in (O.MATH_LIBM, O.MATH_SHARED):
+        st = O.psk_new(O.QPSK, math_mode=mode)
+        re, im = np.zeros(2000), np.zeros(2000)
+        assert L.orc_psk_decode_pulse_shape(iq, 8000, re, im) == 2000
+        assert np.allclose(re, G(golden, f"{src}__real_correlated"), rtol=0, atol=1e-7)
+        assert np.allclose(im, G(golden, f"{src}__imag_correlated"), rtol=0, atol=1e-7)
+        L.orc_psk_timing(C.byref(st), re, im, 2000)
+        assert np.allclose(re, G(golden, f"{src}__real_timesync"), rtol=0, atol=1e-7)
+        assert np.allclose(im, G(golden, f"{src}__imag_timesync"), rtol=0, atol=1e-7)
+        assert L.orc_psk_phase_correction(C.byref(st), re, im, 2000) == 1000
+        pc = G(golden, f"{src}__real_phasecorrect")
+        assert np.array_equal(re[:1000], pc)
+        L.orc_psk_ambiguity(C.byref(st), re, 1000, None, 0)
+        amb = G(golden, f"{src}__real_phaseambcorrect")
+        assert np.array_equal(re[81:1000], amb[: 1000 - 81])
+        # end to end through demodulate()
+        st2 = O.psk_new(O.QPSK, math_mode=mode)
+        out = O.psk_demodulate(st2, iq)
+        assert out.size == 1000
+        assert np.array_equal(out[81:], amb[: 1000 - 81])
+
+
+# ----------------------------------------------------------------------------- shared math vs libm
+
+def test_shared_math_close_to_libm():
+    """include/sdrx_math.h must sit within a few ulp of libm so that the GPU-side definition
+    makes the same decisions as the reference's libm calls (measured, not assumed)."""
+    rng = np.random.default_rng(7)
+    re = rng.uniform(-100, 100, 200000)
+    im = rng.uniform(-100, 100, 200000)
+    a = O.fm_discriminator(re, im, math_mode=O.MATH_LIBM)
+    b = O.fm_discriminator(re, im, math_mode=O.MATH_SHARED)
+    assert np.max(np.abs(a - b)) <= 4 * np.finfo(np.float64).eps * np.pi
+    want = np.angle((re[1:] + 1j * im[1:]) * np.conj(re[:-1] + 1j * im[:-1]))
+    assert np.max(np.abs(a[1:] - want)) < 1e-14
+
+
+def test_chain_streaming_equals_one_shot():
+    """Filter state is carried across execute() calls (filt.cpp:256-259): chunked == one shot."""
+    rng = np.random.default_rng(3)
+    n = 4096
+    re = rng.integers(-127, 128, n).astype(np.float64)
+    im = rng.integers(-127, 128, n).astype(np.float64)
+    err, taps = O.fir_design(O.LPF, 64, 2.4e6, 1.0e5)
+    assert err == 0
+    hI, hQ, pre = np.zeros(63), np.zeros(63), np.zeros(2)
+    out = np.zeros(n // 10 + 2)
+    m = L.orc_chain_fir_decim_disc(taps, 64, hI, hQ, pre, re, im, n, 10, out, O.MATH_SHARED)
+    hI2, hQ2, pre2 = np.zeros(63), np.zeros(63), np.zeros(2)
+    parts = []
+    for k in range(0, n, 1000):
+        r, i = re[k:k + 1000].copy(), im[k:k + 1000].copy()
+        o = np.zeros(102)
+        mm = L.orc_chain_fir_decim_disc(taps, 64, hI2, hQ2, pre2, r, i, r.size, 10, o, O.MATH_SHARED)
+        parts.append(o[:mm])
+    assert np.array_equal(np.concatenate(parts)[:m], out[:m])

@@ -1,0 +1,157 @@
+"""Validate the C restatement (oracle/sdr_oracle.c) bit-for-bit against the REFERENCE's own
+classes compiled from /root/reference (oracle/_ref/libsdr_ref.so, `make -C oracle ref`).
+Skipped where that library was not built (the reference sources do not travel); the
+committed fixtures in tests/golden/ref_fixtures.npz carry the same comparison everywhere
+(tests/test_ref_fixtures.py).  CPU only.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from signals import psk_test_signal
+
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (reference absent)")
+
+L = O.lib()
+
+
+def _ref_fir(ftype, T, Fs, Fx, Fu=None):
+    R = O.ref()
+    return R.ref_fir_new(ftype, 0 if Fu is None else 1, T, Fs, Fx, 0.0 if Fu is None else Fu)
+
+
+@pytest.mark.parametrize("ftype,Fx,Fu", [(O.LPF, 1.0e5, None), (O.HPF, 3.0e5, None), (O.BPF, 1.0e5, 4.0e5)])
+@pytest.mark.parametrize("T", [1, 2, 51, 64, 129, 1000])
+def test_fir_taps_and_streaming(ftype, Fx, Fu, T):
+    """filt.cpp:45-166,236-273: taps identical; execute() identical across 3 ragged chunks."""
+    R = O.ref()
+    h = _ref_fir(ftype, T, 2.0e6, Fx, Fu)
+    assert R.ref_fir_error(h) == 0
+    mine = O.Fir(ftype, T, 2.0e6, Fx, Fu)
+    assert mine.err == 0
+    taps = np.zeros(T)
+    R.ref_fir_get_taps(h, taps)
+    assert np.array_equal(taps, mine.taps)
+    rng = np.random.default_rng(T * 7 + ftype)
+    x = rng.integers(-127, 128, 3000).astype(np.float64) + rng.uniform(-0.5, 0.5, 3000)
+    mine_fast = O.Fir(ftype, T, 2.0e6, Fx, Fu)
+    for lo, hi in ((0, 1), (1, 1300), (1300, 3000)):
+        a = x[lo:hi].copy()
+        R.ref_fir_execute(h, a, a.size)
+        b = mine.execute(x[lo:hi])
+        c = mine_fast.execute(x[lo:hi], fast=True)
+        assert np.array_equal(a, b)
+        assert np.array_equal(a, c)
+    R.ref_fir_free(h)
+
+
+@pytest.mark.parametrize("args,code", [
+    ((O.LPF, 64, 0.0, 1.0, None), -1), ((O.LPF, 64, 2.0e6, 0.0, None), -2), ((O.LPF, 64, 2.0e6, 1.0e6, None), -2),
+    ((O.LPF, 0, 2.0e6, 1.0e5, None), -3), ((O.LPF, 1001, 2.0e6, 1.0e5, None), -3), ((O.BPF, 64, 2.0e6, 1.0e5, None), -5),
+    ((O.BPF, 64, 0.0, 1.0, 2.0), -10), ((O.BPF, 64, 2.0e6, 2.0e5, 1.0e5), -11), ((O.BPF, 64, 2.0e6, 0.0, 1.0e5), -12),
+    ((O.BPF, 64, 2.0e6, 1.0e5, 1.0e6), -13), ((O.BPF, 1024, 2.0e6, 1.0e5, 2.0e5), -14), ((O.LPF, 64, 2.0e6, 1.0e5, 2.0e5), -16),
+])
+def test_fir_error_codes(args, code):
+    """filt.cpp:54-67,85-99 / filt.h:91-102."""
+    R = O.ref()
+    ftype, T, Fs, Fx, Fu = args
+    h = _ref_fir(ftype, T, Fs, Fx, Fu)
+    assert R.ref_fir_error(h) == code
+    assert O.Fir(ftype, T, Fs, Fx, Fu).err == code
+    R.ref_fir_free(h)
+
+
+def test_am_matches_reference():
+    """AM.h:41-77 on the radio value range, ds in {1, 8, 7} (ragged), incl. exact-threshold points."""
+    R = O.ref()
+    rng = np.random.default_rng(11)
+    n = 10007
+    re = rng.integers(-127, 128, n).astype(np.float64)
+    im = rng.integers(-127, 128, n).astype(np.float64)
+    re[:4] = [80.0, 48.0, 79.99999999999999, 0.0]
+    im[:4] = [0.0, 64.0, 0.0, 80.00000000000001]
+    for ds in (1, 8, 7):
+        a = np.zeros(n, dtype=np.uint8)
+        na = R.ref_am_demodulate(re, im, a, n, ds)
+        b = O.am_demodulate(re, im, ds)
+        assert na == b.size
+        assert np.array_equal(a[:na], b)
+    bits = rng.integers(0, 2, 1000).astype(np.uint8)
+    for len_mod in (8000, 8003, 2500):
+        a = np.full(len_mod, -7.0)
+        b = np.full(len_mod, -7.0)
+        R.ref_am_modulate(bits, 1000, a, len_mod)
+        O.am_modulate(bits, len_mod, out=b)
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kind", [O.BPSK, O.QPSK])
+@pytest.mark.parametrize("phase_deg", [0.0, 90.0, 180.0, 270.0, 33.0])
+def test_psk_chain_matches_reference(kind, phase_deg):
+    """BPSK.cpp / QPSK.cpp end to end over 3 consecutive blocks (state carried): decisions,
+    every loop state double and the confidence counters must be IDENTICAL to the reference
+    (libm mode), and the shared-math mode must make the same decisions."""
+    R = O.ref()
+    uw = 0xDEADBEEF600DF00D
+    if kind == O.BPSK:
+        h = R.ref_bpsk_new(uw, 64)
+        st = O.psk_new(O.BPSK, uw, 64, O.MATH_LIBM)
+        st2 = O.psk_new(O.BPSK, uw, 64, O.MATH_SHARED)
+    else:
+        h = R.ref_qpsk_new(None, 16)
+        st = O.psk_new(O.QPSK, None, 16, O.MATH_LIBM)
+        st2 = O.psk_new(O.QPSK, None, 16, O.MATH_SHARED)
+    for blk in range(3):
+        iq = psk_test_signal(kind, nsym=1024, seed=100 * blk + int(phase_deg), phase_deg=phase_deg, snr_db=20.0,
+                             timing_offset=3, uw_bpsk=uw)
+        n = iq.size // 2
+        a = np.zeros(n)
+        na = (R.ref_bpsk_demodulate if kind == O.BPSK else R.ref_qpsk_demodulate)(h, iq, n, a, None)
+        b = O.psk_demodulate(st, iq)
+        b2 = O.psk_demodulate(st2, iq)
+        assert na == b.size == n // 8
+        assert np.array_equal(a[:na], b)
+        assert np.array_equal(b, b2)
+        s = np.zeros(24)
+        cc = np.zeros(4, dtype=np.int32)
+        (R.ref_bpsk_state if kind == O.BPSK else R.ref_qpsk_state)(h, s, cc)
+        assert np.array_equal(s, st.loop_state())
+        ncc = 1 if kind == O.BPSK else 4
+        assert list(cc[:ncc]) == list(st.cc)[:ncc]
+        assert np.allclose(st.loop_state(), st2.loop_state(), rtol=0, atol=1e-9)
+    (R.ref_bpsk_free if kind == O.BPSK else R.ref_qpsk_free)(h)
+
+
+def test_psk_modulators_match_reference():
+    """BPSK.cpp:96-146 / QPSK.cpp:127-188 including the byte-count memset: outputs beyond the first
+    len_mod/8 doubles accumulate onto what the caller left there."""
+    R = O.ref()
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2, 500).astype(np.uint8)
+    sym = rng.integers(0, 4, 500).astype(np.uint8)
+    prior = rng.uniform(-1, 1, 4000)
+    h = R.ref_bpsk_new(0x4E, 8)
+    a, b = prior.copy(), prior.copy()
+    R.ref_bpsk_modulate(h, bits, 500, a, 4000)
+    L.orc_bpsk_modulate(bits, 500, b, 4000)
+    assert np.array_equal(a, b)
+    R.ref_bpsk_free(h)
+    q = R.ref_qpsk_new(None, 16)
+    ar, ai, br, bi = prior.copy(), prior[::-1].copy(), prior.copy(), prior[::-1].copy()
+    R.ref_qpsk_modulate(q, sym, 500, ar, ai, 4000)
+    L.orc_qpsk_modulate(sym, 500, br, bi, 4000)
+    assert np.array_equal(ar, br) and np.array_equal(ai, bi)
+    R.ref_qpsk_free(q)
+
+
+def test_resample_helpers_match_reference():
+    """Resample.h:33-52 (incl. the tail-clear quirk) and Resample.cpp:24-36."""
+    R = O.ref()
+    rng = np.random.default_rng(9)
+    for n, by in ((1000, 2), (1001, 4), (17, 5), (8, 8), (3, 10)):
+        x = rng.uniform(-1, 1, n)
+        a, b = x.copy(), x.copy()
+        assert R.ref_decimate(a, n, by) == L.orc_decimate(b, n, by)
+        assert np.array_equal(a, b)
