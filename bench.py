@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s through the FIR + demod chain on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1|cfg3|cfg4]
+
+Default workload = BASELINE.json configs[1] (cfg2): one synthetic 2.4 MSPS I/Q stream,
+64-tap Filter(LPF) on I and Q -> decimate by 10 -> phase-difference discriminator, fp64.
+One "step" = one pass of the fused chain over a 2^28-sample block of the stream, already
+resident in HBM (interleaved complex fp64 = 4 GiB), Filter/discriminator state carried from
+step to step.  N > 1: one process per GPU (torch.distributed over RCCL for the barrier and
+the max-over-ranks only), every rank runs its own independent stream -- weak scaling, no
+data-path collective.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from sdr_amd import _lib, device  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def synth_fm_stream(n, seed, dev, fs=2.4e6, dev_hz=75e3, tone=1000.0, amp=100.0):
+    """FM-modulated tone quantised to the radio's integer range, interleaved complex fp64 (1, n, 2)."""
+    out = torch.empty(1, n, 2, dtype=torch.float64, device=dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    chunk = 1 << 24
+    beta = dev_hz / tone
+    for k in range(0, n, chunk):
+        m = min(chunk, n - k)
+        t = (torch.arange(k, k + m, device=dev, dtype=torch.float64)) / fs
+        ph = beta * torch.sin(2 * np.pi * tone * t)
+        noise = torch.randn(m, 2, generator=g, device=dev, dtype=torch.float64) * 4.0
+        out[0, k:k + m, 0] = torch.round(amp * torch.cos(ph) + noise[:, 0]).clamp_(-127, 127)
+        out[0, k:k + m, 1] = torch.round(amp * torch.sin(ph) + noise[:, 1]).clamp_(-127, 127)
+    return out
+
+
+def lpf_taps(T, Fs, Fx):
+    taps = np.zeros(T)
+    err = _lib.lib().sdrx_fir_design(_lib.LPF, 0, T, Fs, Fx, 0.0, 1 << 20, taps.ctypes.data)
+    assert err == 0, err
+    return taps
+
+
+def cpu_baseline_cfg2(taps, D, sample_log2=26):
+    """The CPU restatement of the reference chain (oracle/, kind "port"), single thread, literal
+    shift-register Filter (filt.cpp:248-273) on I and on Q, decimate, libm atan2 discriminator."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    L = O.lib()
+    n = 1 << sample_log2
+    rng = np.random.default_rng(1)
+    re = rng.integers(-127, 128, n).astype(np.float64)
+    im = rng.integers(-127, 128, n).astype(np.float64)
+    T = taps.size
+    srI, srQ, pre = np.zeros(T), np.zeros(T), np.zeros(2)
+    out = np.zeros(n // D + 2)
+    t0 = time.perf_counter()
+    L.orc_fir_execute(taps, T, srI, re, n)
+    L.orc_fir_execute(taps, T, srQ, im, n)
+    m = L.orc_decimate(re, n, D)
+    L.orc_decimate(im, n, D)
+    L.orc_fm_discriminator(re, im, m, pre, out, O.MATH_LIBM)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"2^{sample_log2} samples of the cfg2 chain (oracle/sdr_oracle.c, gcc -O2 -ffp-contract=off), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--log2n", type=int, default=0, help="override samples per step (log2)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--fast-fma", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    device.init(local_rank)
+    n_gpus = world if world > 1 else 1
+
+    wl = args.workload
+    cfg = {}
+    if wl in ("cfg2", "cfg4"):
+        D, T, Fs = 10, 64, 2.4e6
+        taps = lpf_taps(T, Fs, 1.0e5)
+        if wl == "cfg2":
+            nchan, n = 1, 1 << (args.log2n or 28)
+            x = synth_fm_stream(n, 1000 + rank, dev)
+        else:
+            nchan, n = 1024, 1 << (args.log2n or 18)
+            x = synth_fm_stream(nchan * n, 1000 + rank, dev).view(nchan, n, 2)
+        chain = device.FirChain(taps, nchan=nchan, decim=D, device=dev)
+        out = torch.zeros(nchan, chain.n_out(n), dtype=torch.float64, device=dev)
+        step = lambda: chain.fir_fmdisc(x, out, fast_fma=args.fast_fma)  # noqa: E731
+        units = nchan * n
+        bytes_per_sample = 16.0 + 8.0 / D
+        kernel = "fir_tile_kernel<R=1, IQ_INTERLEAVED, EPI_DISC>"
+        cfg = {"workload": f"{wl}: Filter(LPF,64,2.4e6,1e5) on I,Q -> decimate 10 -> phase-difference discriminator",
+               "channels_per_gpu": nchan, "samples_per_channel_per_step": n, "layout": "interleaved complex fp64",
+               "parallelism": f"{n_gpus} independent stream set(s), no collective"}
+    elif wl == "cfg1":
+        T, Fs = 64, 2.0e6
+        taps = lpf_taps(T, Fs, 1.0e5)
+        nchan, n = 1, 1 << (args.log2n or 28)
+        x = synth_fm_stream(n, 1000 + rank, dev)
+        chain = device.FirChain(taps, nchan=nchan, decim=1, device=dev)
+        out = torch.zeros(nchan, n, dtype=torch.uint8, device=dev)
+        step = lambda: chain.fir_am(x, out, fast_fma=args.fast_fma)  # noqa: E731
+        units = n
+        bytes_per_sample = 17.0
+        kernel = "fir_tile_kernel<R=8, IQ_INTERLEAVED, EPI_AM>"
+        cfg = {"workload": "cfg1: Filter(LPF,64,2e6,1e5) on I,Q -> AM envelope threshold (ds=1)",
+               "channels_per_gpu": 1, "samples_per_channel_per_step": n, "layout": "interleaved complex fp64",
+               "parallelism": f"{n_gpus} independent stream(s), no collective"}
+    else:  # cfg3
+        nchan, n = 1 << 14, 1 << ((args.log2n or 26) - 14)
+        g = torch.Generator(device=dev).manual_seed(7 + rank)
+        x = torch.randn(nchan, n, 2, generator=g, device=dev, dtype=torch.float64) * 0.3
+        bank = device.PskBank(_lib.QPSK, nchan, n, device=dev)
+        out = torch.zeros(nchan, bank.n_dec, dtype=torch.uint8, device=dev)
+        step = lambda: bank.demod(x, out)  # noqa: E731
+        units = nchan * n
+        bytes_per_sample = 16.125
+        kernel = "psk_loops_kernel"
+        cfg = {"workload": "cfg3: QPSK matched filter /4 -> timing loop -> carrier loop /2 -> UW ambiguity",
+               "channels_per_gpu": nchan, "samples_per_channel_per_step": n, "layout": "interleaved complex fp64",
+               "parallelism": f"{n_gpus} x {nchan} independent channels, no collective"}
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        launch_s = ev_ms / 1e3 / args.steps  # HIP events on the launch stream, averaged over the timed steps
+        achieved = bytes_per_sample * units / launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{wl}.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "Msamples/sec through FIR+demod chain",
+            "value": n_gpus * units * args.steps / dt / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": cfg,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_sample": bytes_per_sample, "launch_ms": launch_s * 1e3},
+        }
+        if n_gpus == 1 and not args.no_cpu and wl == "cfg2":
+            res["cpu_baseline"] = cpu_baseline_cfg2(taps, 10)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,211 @@
+/*
+ * sdrx.h -- C ABI of libsdrx.so: the MI355X (gfx950) implementation of RadioNode's
+ * baseband DSP hot path (FIR Filter + AM / FM / BPSK / QPSK modulators, demodulators).
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  Three layers:
+ *   1. device layer  (sdrx_*_dev)  : device pointers + a hipStream_t (void*), asynchronous,
+ *                                    nothing allocated per call.  This is what bench.py times.
+ *   2. host layer    (sdrx_fir_*, sdrx_am_*, sdrx_fm_*, sdrx_psk_*) : host pointers, the
+ *                                    reference's class methods one-to-one; pinned staging +
+ *                                    hipMemcpyAsync on a per-object stream; synchronous return.
+ *                                    include/sdrx/ (C++ headers) wraps these in the reference's class names.
+ *   3. legacy layer  (am_gpu_*, fm_gpu_*, ones_zeros_demodulation) : the reference's own
+ *                                    extern "C" GPU entry points, byte-for-byte signatures.
+ *
+ * Every entry point cites the reference interface it replaces.  All arithmetic is IEEE fp64
+ * with the reference's operation order and no FMA contraction, so filtered samples, bits and
+ * symbol decisions are bit-identical to RadioNode's CPU path (see DESIGN.md for the two
+ * transcendental exceptions: device sincos/atan2 are include/sdrx_math.h).
+ *
+ * Return convention for new symbols: 0 = SDRX_OK, negative = error (sdrx_last_error()).
+ */
+#ifndef SDRX_H
+#define SDRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRX_OK 0
+#define SDRX_EINVAL (-1)      /* bad argument (null pointer, zero taps, ...) */
+#define SDRX_EHIP (-2)        /* a HIP runtime call failed */
+#define SDRX_EUNSUPPORTED (-3) /* shape outside the kernels' limits */
+#define SDRX_ENOMEM (-4)
+
+/* sample layouts at the device boundary */
+#define SDRX_REAL 0           /* one rail: in0 = T[n] */
+#define SDRX_IQ_SPLIT 1       /* in0 = re[n], in1 = im[n]  (AM.h:63, FM.h:112, rtlsdr_receiver.cpp:1994-1995) */
+#define SDRX_IQ_INTERLEAVED 2 /* in0 = {re,im}[n] = std::complex<double>[n] (Common_Deffinitions.h:12-13, BBP_Block.h:14) */
+
+/* Filter::filterType, filt.h:131 */
+#define SDRX_LPF 0
+#define SDRX_HPF 1
+#define SDRX_BPF 2
+/* filt.h:121 */
+#define SDRX_REF_MAX_TAPS 1000
+
+#define SDRX_BPSK 0
+#define SDRX_QPSK 1
+
+/* ------------------------------------------------------------------ library */
+int sdrx_init(int device);           /* hipSetDevice + constants; idempotent per device */
+int sdrx_device_count(void);
+const char *sdrx_last_error(void);   /* thread-local message of the last failure */
+const char *sdrx_version(void);
+
+/* ------------------------------------------------------------------ 1. device layer */
+
+/*
+ * One FIR (+ fused epilogue) job over `nchan` independent channels.
+ *   y[c][m] = sum_{k=0}^{T-1} x[c][m*D + phase - k] * h[k]      (k ascending: filt.cpp:261-262)
+ * x[c][i<0] comes from the channel's carried history (Filter's shift register, filt.cpp:256-259).
+ * State per channel (doubles): hist0[T-1] (x[-1], x[-2], ...), hist1[T-1] (second rail), pre[2].
+ * state_in and state_out must be different buffers (a launch reads one and writes the other);
+ * state_pitch >= 2*(T-1)+2.  Outputs never alias inputs.
+ */
+typedef struct sdrx_fir_job {
+    int layout;               /* SDRX_REAL / SDRX_IQ_SPLIT / SDRX_IQ_INTERLEAVED */
+    int fast_fma;             /* 0: mul then add like the CPU reference (bit-exact); 1: fused FMA (<=1e-12 rel.) */
+    const void *in0, *in1;    /* device */
+    size_t n;                 /* input samples per channel */
+    size_t nchan;
+    size_t in_pitch;          /* samples between consecutive channels */
+    const double *taps;       /* device, num_taps doubles */
+    int num_taps;
+    unsigned decim;           /* D >= 1 */
+    const double *state_in;   /* device, nchan * state_pitch doubles */
+    double *state_out;
+    size_t state_pitch;
+    void *out0, *out1;        /* device; meaning depends on the entry point */
+    size_t out_pitch;         /* output elements between channels */
+    size_t n_out;             /* 0 = ceil(n / D); otherwise exactly this many outputs per channel */
+    void *stream;             /* hipStream_t, NULL = default stream */
+} sdrx_fir_job;
+
+/* Filter::execute (filt.cpp:267-273) on 1 rail (out0) or on I and Q (out0, out1), optionally
+ * keeping every D-th output (decimate<T>, Resample.h:33-52).  Output type double. */
+int sdrx_fir_dev(const sdrx_fir_job *job);
+/* Filter::execute on I and Q, then AM<T>::demodulate with downsample = decim (AM.h:63-77):
+ * out0 = uint8 0/1 per kept sample. */
+int sdrx_fir_am_dev(const sdrx_fir_job *job);
+/* Filter::execute on I and Q, decimate by D, phase-difference discriminator
+ * (rtl_fm.c:422-435, 518-546 in fp64): out0 = double angle (rad) per kept sample. */
+int sdrx_fir_fmdisc_dev(const sdrx_fir_job *job);
+size_t sdrx_fir_state_doubles(int num_taps); /* 2*(T-1)+2 */
+
+/* AM<T>::demodulate (AM.h:63-77) / kernel_am_demod (am.cu:72-81): out[k] = |x[k*ds]| >= 80 */
+int sdrx_am_demod_dev(const double *re, const double *im, uint8_t *out, size_t n, size_t ds, void *stream);
+/* ones/zeros count (rtlsdr_receiver.cpp:2063-2074, ones_zeros.cu:28-52): *count (device int32, zeroed by the call) */
+int sdrx_ones_zeros_dev(const double *re, const double *im, size_t n, int32_t *count, void *stream);
+/* FM<T>::demodulate (FM.h:83-148, repaired): w1/w2 device tables of ds doubles; out[n/ds] bits */
+int sdrx_fm_demod_dev(const double *re, const double *w1, const double *w2, uint8_t *out, size_t n, size_t ds,
+                      void *stream);
+
+/* PSK loop state of one channel: the reference's public loop structs (BPSK.h:130-276) flattened. */
+typedef struct sdrx_psk_state {
+    double nco_delay, reg_mu, reg_Q, reg_I, mu_delay; /* NcoControlVariables.delay, Register_*, muDelay */
+    double iq_d[5], ii_d[5];                           /* Interp_Q_Channel, Interp_I_Channel delay1..5 */
+    double g1, g2, g3, g4;                             /* GardnerDetectorVariables.delay1..4 (start at 1) */
+    double lf_x, lf_y;                                 /* LoopFilterVariables */
+    double dds_delay, plf_x, plf_y;                    /* PhaseCorrectionVariables.dds_delay, PhaseLoopFilterVariables */
+    int32_t cc[4];                                     /* confidence counters: BPSK cc[0]; QPSK 000/090/180/270 */
+    int32_t uw_size;
+    int32_t n_hits;                                    /* UW hits found by the last ambiguity pass */
+    double uw[4][64];                                  /* uw_0/uw_180 or uw_000/090/180/270 (BPSK.h:307-308) */
+} sdrx_psk_state;
+
+void sdrx_psk_state_init_bpsk(sdrx_psk_state *s, uint64_t unique_word, size_t uw_len); /* BPSK.cpp:52-90 (host) */
+void sdrx_psk_state_init_qpsk(sdrx_psk_state *s, const double *uw64, size_t uw_len);   /* QPSK.cpp:66-120 (host) */
+
+/*
+ * BPSK::demodulate / QPSK::demodulate (BPSK.cpp:148-176, QPSK.cpp:190-219) over nchan channels.
+ *   iq        device, interleaved complex fp64, channel c at iq + 2*c*in_pitch doubles, n samples each
+ *   states    device, nchan sdrx_psk_state (read and updated in place)
+ *   out       device uint8: decisions 0/1 (BPSK) or 0..3 (QPSK), n/8 per channel, pitch out_pitch
+ *   work      device workspace of sdrx_psk_work_bytes(n, nchan) bytes
+ */
+size_t sdrx_psk_work_bytes(size_t n, size_t nchan);
+int sdrx_psk_demod_dev(int kind, const double *iq, size_t n, size_t nchan, size_t in_pitch,
+                       sdrx_psk_state *states, uint8_t *out, size_t out_pitch, void *work, void *stream);
+/* stage entry points (the reference keeps every stage public and unit-tested) */
+int sdrx_psk_matched_filter_dev(const double *iq, size_t n, size_t nchan, size_t in_pitch, double *mf_iq,
+                                size_t mf_pitch, void *stream); /* decode_pulseShape: n -> n/4 interleaved */
+int sdrx_psk_loops_dev(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch, sdrx_psk_state *states,
+                       uint8_t *decisions, size_t out_pitch, int run_timing, int run_phase,
+                       void *stream); /* timing (in place on mf_iq) + carrier loop + /2 */
+int sdrx_psk_ambiguity_dev(int kind, uint8_t *decisions, size_t m, size_t nchan, size_t out_pitch,
+                           sdrx_psk_state *states, void *stream);
+/* encode_LUT + encode_pulseShape (BPSK.cpp:112-146, QPSK.cpp:144-188): sym uint8 -> 8*len samples per rail.
+ * out_im NULL for BPSK.  zero_prefix: leading elements treated as zero, the rest accumulate onto prior contents. */
+int sdrx_psk_modulate_dev(int kind, const uint8_t *sym, size_t len, double *out_re, double *out_im,
+                          size_t zero_prefix, void *stream);
+
+/* ------------------------------------------------------------------ 2. host layer (drop-in) */
+
+typedef struct sdrx_fir sdrx_fir_t;
+
+/* Filter::Filter validation + designLPF/HPF/BPF (filt.cpp:45-154), host arithmetic (libm sin). */
+int sdrx_fir_design(int type, int two_freq, int num_taps, double Fs, double Fx, double Fu, int max_taps,
+                    double *taps);
+sdrx_fir_t *sdrx_fir_create(int type, int two_freq, int num_taps, double Fs, double Fx, double Fu, int max_taps);
+void sdrx_fir_destroy(sdrx_fir_t *f);                     /* Filter::~Filter */
+int sdrx_fir_error_flag(const sdrx_fir_t *f);             /* Filter::get_error_flag, filt.h:156 */
+void sdrx_fir_get_taps(const sdrx_fir_t *f, double *taps); /* filt.cpp:156-166 */
+void sdrx_fir_reset(sdrx_fir_t *f);                       /* Filter::init, filt.cpp:236-246 */
+int sdrx_fir_execute(sdrx_fir_t *f, double *buf, size_t n); /* Filter::execute, in place, state carried */
+double sdrx_fir_do_sample(sdrx_fir_t *f, double x);       /* Filter::do_sample (one-sample launch) */
+
+size_t sdrx_am_demodulate(const double *re, const double *im, uint8_t *out, size_t n, size_t ds); /* AM.h:63-77 */
+void sdrx_am_modulate(const uint8_t *bits, size_t len, double *out_real, size_t len_mod);         /* AM.h:41-54 */
+size_t sdrx_fm_demodulate(double rx_rate, double mark, double space, const double *re, uint8_t *out, size_t n,
+                          size_t ds);                                                             /* FM.h:112-148 */
+void sdrx_fm_modulate(double tx_rate, double mark, double space, const uint8_t *bits, size_t len,
+                      double *out_real, size_t spb);                                              /* FM.h:44-74 */
+/* Chains of BASELINE configs 1 and 2 on host buffers (state in the two Filter-like objects). */
+typedef struct sdrx_chain sdrx_chain_t;
+sdrx_chain_t *sdrx_chain_create(const double *taps, int num_taps, unsigned decim);
+void sdrx_chain_destroy(sdrx_chain_t *c);
+void sdrx_chain_reset(sdrx_chain_t *c);
+size_t sdrx_chain_fir_am(sdrx_chain_t *c, const double *re, const double *im, size_t n, uint8_t *bits);
+size_t sdrx_chain_fir_fmdisc(sdrx_chain_t *c, const double *re, const double *im, size_t n, double *angle);
+
+typedef struct sdrx_psk sdrx_psk_t;
+sdrx_psk_t *sdrx_psk_create(int kind, uint64_t bpsk_uw, const double *qpsk_uw64, size_t uw_len);
+void sdrx_psk_destroy(sdrx_psk_t *p);
+void sdrx_psk_get_state(sdrx_psk_t *p, sdrx_psk_state *out);
+void sdrx_psk_set_state(sdrx_psk_t *p, const sdrx_psk_state *in);
+/* BPSK::demodulate(BBP_Block*,BBP_Block*) / QPSK::demodulate: iq = n interleaved complex;
+ * out[n/8] decisions as doubles (real part of the output block; imag is 0).  Returns the count.
+ * hits (may be NULL, capacity max_hits): UW hits as (position << 3 | code) for the "Phase ..." prints. */
+size_t sdrx_psk_demodulate(sdrx_psk_t *p, const double *iq, size_t n, double *out, uint64_t *hits, size_t max_hits);
+/* stage methods on host buffers (BPSK.cpp:213-487 / QPSK.cpp:222-509) */
+size_t sdrx_psk_decode_pulse_shape(sdrx_psk_t *p, const double *iq, size_t n, double *re, double *im);
+void sdrx_psk_timing(sdrx_psk_t *p, double *re, double *im, size_t n);
+size_t sdrx_psk_phase_correction(sdrx_psk_t *p, double *re, double *im, size_t n);
+size_t sdrx_psk_ambiguity(sdrx_psk_t *p, double *re, size_t n, uint64_t *hits, size_t max_hits);
+/* BPSK::modulate / QPSK::modulate (out_imag NULL for BPSK); prior contents beyond len_mod/8 elements accumulate */
+int sdrx_psk_modulate(int kind, const uint8_t *sym, size_t len, double *out_real, double *out_imag, size_t len_mod);
+
+/* ------------------------------------------------------------------ 3. legacy layer */
+/* am.cu:94-152 */
+void am_gpu_initialize(size_t MAX_NUM_POINTS, size_t num_of_radios);
+void am_gpu_free(void);
+double am_gpu_demodulation(int RADIO_ID, double *real, double *imag, uint8_t *output, size_t number_of_points,
+                           size_t ds);
+/* fm.cu:48-167 (demodulation follows the CPU FM<T>::demodulate semantics: see DESIGN.md) */
+void fm_gpu_initialize(size_t num_of_radios, size_t MaxBufferSize, size_t rx_sample_rate, size_t samples_per_bit,
+                       double MARK_FREQ, double SPACE_FREQ);
+void fm_gpu_free(void);
+void fm_gpu_set_samples_per_bit(size_t samples_per_bit, size_t rx_sample_rate);
+double fm_gpu_demodulation(int RADIO_ID, double *real, double *imag, uint8_t *output, size_t number_of_points,
+                           size_t ds);
+/* ones_zeros.cu:28-52 */
+int32_t ones_zeros_demodulation(double *real, double *imag, size_t number_of_points);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRX_H */

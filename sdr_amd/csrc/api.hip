@@ -1,0 +1,1026 @@
+// api.hip -- the C ABI of libsdrx.so (include/sdrx.h): device layer, host (drop-in) layer with
+// pinned staging + async copies, and the reference's legacy extern "C" GPU symbols.
+#include "sdrx_internal.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+namespace sdrx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+double am_threshold_sq()
+{
+    static const double thr2 = [] {
+        double s = 80.0 * 80.0;
+        for (;;) { // IEEE sqrt is monotone: walk down to the first double whose rounded root is below 80
+            double below = std::nextafter(s, 0.0);
+            if (std::sqrt(below) >= 80.0) s = below;
+            else break;
+        }
+        return s;
+    }();
+    return thr2;
+}
+
+// ---- small device scratch cache (stage-level entry points only; the *_dev hot path never allocates)
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return SDRX_OK;
+        if (p) {
+            SDRX_HIP(hipDeviceSynchronize());
+            SDRX_HIP(hipFree(p));
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        SDRX_HIP(hipMalloc(&p, want));
+        cap = want;
+        return SDRX_OK;
+    }
+};
+
+static std::mutex g_mu;
+static double *g_mf_taps = nullptr;
+static int g_mf_taps_dev = -1;
+
+const double *psk_mf_taps_dev()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (g_mf_taps && g_mf_taps_dev == dev) return g_mf_taps;
+    double rev[129];
+    for (int k = 0; k < 129; k++) rev[k] = RRC_COEFF[129 - k - 1]; // h[k] multiplies x[i-k]: BPSK.cpp:283
+    double *p = nullptr;
+    if (hipMalloc((void **)&p, sizeof(rev)) != hipSuccess) return nullptr;
+    if (hipMemcpy(p, rev, sizeof(rev), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    g_mf_taps = p;
+    g_mf_taps_dev = dev;
+    return p;
+}
+
+// Pinned host staging + device mirror, grown on demand, owned by one host-layer object.
+struct Staging {
+    void *host = nullptr;
+    void *dev = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return SDRX_OK;
+        release();
+        size_t want = bytes + bytes / 4 + 4096;
+        SDRX_HIP(hipHostMalloc(&host, want, hipHostMallocDefault));
+        SDRX_HIP(hipMalloc(&dev, want));
+        cap = want;
+        return SDRX_OK;
+    }
+    void release()
+    {
+        if (host) (void)hipHostFree(host);
+        if (dev) (void)hipFree(dev);
+        host = dev = nullptr;
+        cap = 0;
+    }
+};
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+} // namespace sdrx
+
+using namespace sdrx;
+
+// =========================================================================== library
+
+extern "C" int sdrx_init(int device)
+{
+    SDRX_HIP(hipSetDevice(device));
+    SDRX_HIP(hipFree(nullptr));
+    (void)am_threshold_sq();
+    return SDRX_OK;
+}
+
+extern "C" int sdrx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *sdrx_last_error(void) { return g_err; }
+extern "C" const char *sdrx_version(void) { return "sdrx 0.1 (gfx950)"; }
+
+// =========================================================================== 1. device layer
+
+extern "C" size_t sdrx_fir_state_doubles(int num_taps) { return num_taps > 0 ? (size_t)(2 * (num_taps - 1) + 2) : 2; }
+extern "C" int sdrx_fir_dev(const sdrx_fir_job *job) { return launch_fir(job, EPI_STORE); }
+extern "C" int sdrx_fir_am_dev(const sdrx_fir_job *job) { return launch_fir(job, EPI_AM); }
+extern "C" int sdrx_fir_fmdisc_dev(const sdrx_fir_job *job) { return launch_fir(job, EPI_DISC); }
+
+extern "C" int sdrx_am_demod_dev(const double *re, const double *im, uint8_t *out, size_t n, size_t ds, void *stream)
+{
+    return launch_am_demod(re, im, out, n, ds, (hipStream_t)stream);
+}
+extern "C" int sdrx_ones_zeros_dev(const double *re, const double *im, size_t n, int32_t *count, void *stream)
+{
+    return launch_ones_zeros(re, im, n, count, (hipStream_t)stream);
+}
+extern "C" int sdrx_fm_demod_dev(const double *re, const double *w1, const double *w2, uint8_t *out, size_t n,
+                                 size_t ds, void *stream)
+{
+    return launch_fm_demod(re, w1, w2, out, n, ds, (hipStream_t)stream);
+}
+
+// ---- PSK state (host arithmetic only: constructor logic of BPSK.cpp:52-90 / QPSK.cpp:66-120)
+static void psk_state_common(sdrx_psk_state *s, size_t uw_len)
+{
+    memset(s, 0, sizeof(*s));
+    s->g1 = s->g2 = s->g3 = s->g4 = 1.0;          // BPSK.cpp:68-71
+    for (int i = 0; i < 4; i++) s->cc[i] = 10 / 2; // confidence_counter(10,5,5) starts at max/2
+    s->uw_size = (int32_t)uw_len;
+}
+
+extern "C" void sdrx_psk_state_init_bpsk(sdrx_psk_state *s, uint64_t unique_word, size_t uw_len)
+{
+    psk_state_common(s, uw_len);
+    if (uw_len > 64) return; // BPSK.cpp:79
+    for (int i = (int)uw_len - 1; i >= 0; i--) {
+        uint64_t mask = 1ULL << i;
+        s->uw[0][i] = ((unique_word & mask) > 0) ? 1 : 0;
+        s->uw[1][i] = ((unique_word & mask) > 0) ? 0 : 1;
+    }
+}
+
+extern "C" void sdrx_psk_state_init_qpsk(sdrx_psk_state *s, const double *uw64, size_t uw_len)
+{
+    static const double dflt[64] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                    0, 0, 0, 0, 3, 0, 2, 1, 0, 3, 2, 1, 2, 0, 1, 2, 3, 2, 2, 3}; // QPSK.cpp:20-28
+    static const double l000[4] = {0, 1, 2, 3}, l090[4] = {2, 0, 3, 1}, l180[4] = {3, 2, 1, 0}, l270[4] = {1, 3, 0, 2};
+    psk_state_common(s, uw_len);
+    if (!uw64) uw64 = dflt;
+    if (uw_len > 64) return; // QPSK.cpp:96
+    for (int i = 63; i >= 64 - (int)uw_len && i >= 0; i--) {
+        if (uw64[i] >= 0 && uw64[i] <= 3) {
+            const int v = (int)uw64[i];
+            s->uw[0][i] = l000[v];
+            s->uw[1][i] = l270[v]; // uw_090 <- LUT_REAL_270, QPSK.cpp:107
+            s->uw[2][i] = l180[v];
+            s->uw[3][i] = l090[v]; // uw_270 <- LUT_REAL__90, QPSK.cpp:109
+        }
+    }
+}
+
+static const size_t MF_T = 129, MF_STATE = 2 * (MF_T - 1) + 2;
+
+extern "C" size_t sdrx_psk_work_bytes(size_t n, size_t nchan)
+{
+    return align256(nchan * (n / 4) * 2 * sizeof(double)) + 2 * align256(nchan * MF_STATE * sizeof(double));
+}
+
+static int mf_launch(const double *iq, size_t n, size_t nchan, size_t in_pitch, double *mf_iq, size_t mf_pitch,
+                     double *zero_state, double *dummy_state, hipStream_t stream)
+{
+    const double *taps = psk_mf_taps_dev();
+    if (!taps) {
+        set_error("matched-filter taps upload failed");
+        return SDRX_EHIP;
+    }
+    if (n / 4 == 0) return SDRX_OK;
+    // decode_pulseShape re-pads with zeros on every call (BPSK.cpp:267-268): zero history, nothing carried
+    SDRX_HIP(hipMemsetAsync(zero_state, 0, nchan * MF_STATE * sizeof(double), stream));
+    sdrx_fir_job j;
+    memset(&j, 0, sizeof(j));
+    j.layout = SDRX_IQ_INTERLEAVED;
+    j.in0 = iq;
+    j.n = n;
+    j.nchan = nchan;
+    j.in_pitch = in_pitch;
+    j.taps = taps;
+    j.num_taps = (int)MF_T;
+    j.decim = 4; // decimate(.., 4): BPSK.cpp:289-290
+    j.state_in = zero_state;
+    j.state_out = dummy_state;
+    j.state_pitch = MF_STATE;
+    j.out0 = mf_iq;
+    j.out1 = nullptr;
+    j.out_pitch = mf_pitch;
+    j.n_out = n / 4; // memcpy of number_of_points/4 values: BPSK.cpp:292-293
+    j.stream = stream;
+    return launch_fir(&j, EPI_STORE);
+}
+
+extern "C" int sdrx_psk_demod_dev(int kind, const double *iq, size_t n, size_t nchan, size_t in_pitch,
+                                  sdrx_psk_state *states, uint8_t *out, size_t out_pitch, void *work, void *stream)
+{
+    if (!iq || !states || !out || !work) {
+        set_error("sdrx_psk_demod_dev: null pointer");
+        return SDRX_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t m = n / 4;
+    unsigned char *w = (unsigned char *)work;
+    double *mf = (double *)w;
+    double *zst = (double *)(w + align256(nchan * m * 2 * sizeof(double)));
+    double *dst = (double *)((unsigned char *)zst + align256(nchan * MF_STATE * sizeof(double)));
+    int rc = mf_launch(iq, n, nchan, in_pitch, mf, m, zst, dst, s);
+    if (rc) return rc;
+    rc = launch_psk_loops(kind, mf, m, nchan, m, states, out, out_pitch, 1, 1, s);
+    if (rc) return rc;
+    return launch_psk_ambiguity(kind, out, (m + 1) / 2, nchan, out_pitch, states, s);
+}
+
+static Scratch g_mf_scratch;
+
+extern "C" int sdrx_psk_matched_filter_dev(const double *iq, size_t n, size_t nchan, size_t in_pitch, double *mf_iq,
+                                           size_t mf_pitch, void *stream)
+{
+    if (!iq || !mf_iq) return SDRX_EINVAL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t st_bytes = align256(nchan * MF_STATE * sizeof(double));
+    int rc = g_mf_scratch.ensure(2 * st_bytes);
+    if (rc) return rc;
+    return mf_launch(iq, n, nchan, in_pitch, mf_iq, mf_pitch, (double *)g_mf_scratch.p,
+                     (double *)((unsigned char *)g_mf_scratch.p + st_bytes), (hipStream_t)stream);
+}
+
+extern "C" int sdrx_psk_loops_dev(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch,
+                                  sdrx_psk_state *states, uint8_t *decisions, size_t out_pitch, int run_timing,
+                                  int run_phase, void *stream)
+{
+    return launch_psk_loops(kind, mf_iq, m, nchan, mf_pitch, states, decisions, out_pitch, run_timing, run_phase,
+                            (hipStream_t)stream);
+}
+
+extern "C" int sdrx_psk_ambiguity_dev(int kind, uint8_t *decisions, size_t m, size_t nchan, size_t out_pitch,
+                                      sdrx_psk_state *states, void *stream)
+{
+    return launch_psk_ambiguity(kind, decisions, m, nchan, out_pitch, states, (hipStream_t)stream);
+}
+
+extern "C" int sdrx_psk_modulate_dev(int kind, const uint8_t *sym, size_t len, double *out_re, double *out_im,
+                                     size_t zero_prefix, void *stream)
+{
+    return launch_psk_modulate(kind, sym, len, out_re, out_im, zero_prefix, (hipStream_t)stream);
+}
+
+// =========================================================================== 2. host layer
+
+extern "C" int sdrx_fir_design(int type, int two_freq, int num_taps, double Fs, double Fx, double Fu, int max_taps,
+                               double *taps)
+{
+    const double lambda = M_PI * Fx / (Fs / 2); // filt.cpp:52
+    if (!two_freq) {                            // filt.cpp:54-67
+        if (Fs <= 0) return -1;
+        if (Fx <= 0 || Fx >= Fs / 2) return -2;
+        if (num_taps <= 0 || num_taps > max_taps) return -3;
+        if (type != SDRX_LPF && type != SDRX_HPF) return -5;
+        for (int n = 0; n < num_taps; n++) { // filt.cpp:116-120, 131-135
+            const double mm = n - (num_taps - 1.0) / 2.0;
+            if (type == SDRX_LPF) taps[n] = (mm == 0.0) ? lambda / M_PI : sin(mm * lambda) / (mm * M_PI);
+            else taps[n] = (mm == 0.0) ? 1.0 - lambda / M_PI : -sin(mm * lambda) / (mm * M_PI);
+        }
+        return 0;
+    }
+    const double phi = M_PI * Fu / (Fs / 2); // filt.cpp:83
+    if (Fs <= 0) return -10;                 // filt.cpp:85-99
+    if (Fx >= Fu) return -11;
+    if (Fx <= 0 || Fx >= Fs / 2) return -12;
+    if (Fu <= 0 || Fu >= Fs / 2) return -13;
+    if (num_taps <= 0 || num_taps > max_taps) return -14;
+    if (type != SDRX_BPF) return -16;
+    for (int n = 0; n < num_taps; n++) { // filt.cpp:146-151
+        const double mm = n - (num_taps - 1.0) / 2.0;
+        taps[n] = (mm == 0.0) ? (phi - lambda) / M_PI : (sin(mm * phi) - sin(mm * lambda)) / (mm * M_PI);
+    }
+    return 0;
+}
+
+struct sdrx_fir {
+    int err = 0;
+    int T = 0;
+    std::vector<double> taps;
+    double *d_taps = nullptr;
+    double *d_state[2] = {nullptr, nullptr};
+    int cur = 0;
+    hipStream_t stream = nullptr;
+    Staging in, out;
+};
+
+static int fir_alloc_device(sdrx_fir *f)
+{
+    const size_t sd = sdrx_fir_state_doubles(f->T);
+    SDRX_HIP(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    SDRX_HIP(hipMalloc((void **)&f->d_taps, f->T * sizeof(double)));
+    SDRX_HIP(hipMemcpy(f->d_taps, f->taps.data(), f->T * sizeof(double), hipMemcpyHostToDevice));
+    for (int i = 0; i < 2; i++) {
+        SDRX_HIP(hipMalloc((void **)&f->d_state[i], sd * sizeof(double)));
+        SDRX_HIP(hipMemset(f->d_state[i], 0, sd * sizeof(double)));
+    }
+    return SDRX_OK;
+}
+
+extern "C" sdrx_fir_t *sdrx_fir_create(int type, int two_freq, int num_taps, double Fs, double Fx, double Fu,
+                                       int max_taps)
+{
+    sdrx_fir *f = new sdrx_fir();
+    f->T = num_taps;
+    f->taps.assign(num_taps > 0 ? (size_t)num_taps : 1, 0.0);
+    f->err = sdrx_fir_design(type, two_freq, num_taps, Fs, Fx, Fu, max_taps, f->taps.data());
+    if (f->err == 0 && fir_alloc_device(f) != SDRX_OK) f->err = -4; // "memory allocation ... failed", filt.h:94
+    return f;
+}
+
+extern "C" void sdrx_fir_destroy(sdrx_fir_t *f)
+{
+    if (!f) return;
+    if (f->stream) (void)hipStreamSynchronize(f->stream);
+    if (f->d_taps) (void)hipFree(f->d_taps);
+    for (int i = 0; i < 2; i++)
+        if (f->d_state[i]) (void)hipFree(f->d_state[i]);
+    f->in.release();
+    f->out.release();
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+
+extern "C" int sdrx_fir_error_flag(const sdrx_fir_t *f) { return f ? f->err : -4; }
+
+extern "C" void sdrx_fir_get_taps(const sdrx_fir_t *f, double *taps)
+{
+    if (!f || f->err != 0) return; // filt.cpp:161
+    for (int i = 0; i < f->T; i++) taps[i] = f->taps[i];
+}
+
+extern "C" void sdrx_fir_reset(sdrx_fir_t *f)
+{
+    if (!f || f->err != 0) return; // filt.cpp:241
+    (void)hipStreamSynchronize(f->stream);
+    for (int i = 0; i < 2; i++) (void)hipMemset(f->d_state[i], 0, sdrx_fir_state_doubles(f->T) * sizeof(double));
+}
+
+extern "C" int sdrx_fir_execute(sdrx_fir_t *f, double *buf, size_t n)
+{
+    if (!f || !buf) return SDRX_EINVAL;
+    if (f->err != 0) { // do_sample returns 0 once the error flag is set: filt.cpp:254
+        for (size_t i = 0; i < n; i++) buf[i] = 0.0;
+        return SDRX_OK;
+    }
+    if (n == 0) return SDRX_OK;
+    const size_t bytes = n * sizeof(double);
+    int rc = f->in.ensure(bytes);
+    if (rc) return rc;
+    rc = f->out.ensure(bytes);
+    if (rc) return rc;
+    memcpy(f->in.host, buf, bytes);
+    SDRX_HIP(hipMemcpyAsync(f->in.dev, f->in.host, bytes, hipMemcpyHostToDevice, f->stream));
+    sdrx_fir_job j;
+    memset(&j, 0, sizeof(j));
+    j.layout = SDRX_REAL;
+    j.in0 = f->in.dev;
+    j.n = n;
+    j.nchan = 1;
+    j.in_pitch = n;
+    j.taps = f->d_taps;
+    j.num_taps = f->T;
+    j.decim = 1;
+    j.state_in = f->d_state[f->cur];
+    j.state_out = f->d_state[f->cur ^ 1];
+    j.state_pitch = sdrx_fir_state_doubles(f->T);
+    j.out0 = f->out.dev;
+    j.out_pitch = n;
+    j.stream = f->stream;
+    rc = launch_fir(&j, EPI_STORE);
+    if (rc) return rc;
+    f->cur ^= 1;
+    SDRX_HIP(hipMemcpyAsync(f->out.host, f->out.dev, bytes, hipMemcpyDeviceToHost, f->stream));
+    SDRX_HIP(hipStreamSynchronize(f->stream));
+    memcpy(buf, f->out.host, bytes);
+    return SDRX_OK;
+}
+
+extern "C" double sdrx_fir_do_sample(sdrx_fir_t *f, double x)
+{
+    double v = x;
+    if (sdrx_fir_execute(f, &v, 1) != SDRX_OK) return 0.0;
+    return v;
+}
+
+// ---- AM / FM on host buffers
+struct HostCtx { // one per thread: a stream and staging for the stateless host-layer calls
+    hipStream_t stream = nullptr;
+    Staging a, b, c;
+    int ready()
+    {
+        if (!stream) SDRX_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return SDRX_OK;
+    }
+};
+static thread_local HostCtx t_ctx;
+
+extern "C" size_t sdrx_am_demodulate(const double *re, const double *im, uint8_t *out, size_t n, size_t ds)
+{
+    if (!re || !im || !out || ds == 0 || n == 0) return 0;
+    HostCtx &c = t_ctx;
+    const size_t bytes = n * sizeof(double), n_out = (n + ds - 1) / ds;
+    if (c.ready() || c.a.ensure(bytes) || c.b.ensure(bytes) || c.c.ensure(n_out + 8)) {
+        printf("[HIP][sdrx_am_demodulate] Error! %s\n", g_err); // print-and-continue: am.cu:143-146
+        return 0;
+    }
+    memcpy(c.a.host, re, bytes);
+    memcpy(c.b.host, im, bytes);
+    bool ok = hipMemcpyAsync(c.a.dev, c.a.host, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              hipMemcpyAsync(c.b.dev, c.b.host, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              launch_am_demod((double *)c.a.dev, (double *)c.b.dev, (uint8_t *)c.c.dev, n, ds, c.stream) == SDRX_OK &&
+              hipMemcpyAsync(c.c.host, c.c.dev, n_out, hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+              hipStreamSynchronize(c.stream) == hipSuccess;
+    if (!ok) {
+        printf("[HIP][sdrx_am_demodulate] Error! %s\n", g_err);
+        return 0;
+    }
+    memcpy(out, c.c.host, n_out);
+    return n_out; // out_index of AM.h:76
+}
+
+extern "C" void sdrx_am_modulate(const uint8_t *bits, size_t len, double *out_real, size_t len_mod)
+{
+    // AM.h:41-54 + raw_upsample (Resample.h:15-27): a bit-repeat copy, no arithmetic; done where the
+    // data lives (host buffers in, host buffers out).
+    if (!bits || !out_real || len == 0) return;
+    const double ratio = (double)len_mod / (double)len;
+    const double rep = floor(ratio);
+    size_t oi = 0;
+    for (size_t ii = 0; oi < len_mod && ii < len; ii++)
+        for (int j = 0; (j < rep) && (oi < len_mod); j++) out_real[oi++] = (double)bits[ii];
+}
+
+static void fm_waves(double rate, double mark, double space, size_t ds, std::vector<double> &w1,
+                     std::vector<double> &w2)
+{
+    const double PI = 3.141592653589793238460; // Common_Deffinitions.h:14
+    const double delta_t = 1.0 / rate;         // FM.h:125
+    w1.resize(ds);
+    w2.resize(ds);
+    for (size_t i = 0; i < ds; i++) { // FM.h:127-131: host-built tables, as fm.cu:62-68 does
+        w1[i] = sqrt(2.0 / ds) * cos(2.0 * PI * mark * i * delta_t);
+        w2[i] = sqrt(2.0 / ds) * cos(2.0 * PI * space * i * delta_t);
+    }
+}
+
+extern "C" size_t sdrx_fm_demodulate(double rx_rate, double mark, double space, const double *re, uint8_t *out,
+                                     size_t n, size_t ds)
+{
+    if (!re || !out || ds == 0) return 0;
+    const size_t nbits = n / ds;
+    if (nbits == 0) return 0;
+    HostCtx &c = t_ctx;
+    std::vector<double> w1, w2;
+    fm_waves(rx_rate, mark, space, ds, w1, w2);
+    const size_t bytes = n * sizeof(double), wbytes = ds * sizeof(double);
+    if (c.ready() || c.a.ensure(bytes) || c.b.ensure(2 * wbytes) || c.c.ensure(nbits + 8)) {
+        printf("[HIP][sdrx_fm_demodulate] Error! %s\n", g_err);
+        return 0;
+    }
+    memcpy(c.a.host, re, bytes);
+    memcpy(c.b.host, w1.data(), wbytes);
+    memcpy((char *)c.b.host + wbytes, w2.data(), wbytes);
+    bool ok = hipMemcpyAsync(c.a.dev, c.a.host, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              hipMemcpyAsync(c.b.dev, c.b.host, 2 * wbytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              launch_fm_demod((double *)c.a.dev, (double *)c.b.dev, (double *)c.b.dev + ds, (uint8_t *)c.c.dev, n, ds,
+                              c.stream) == SDRX_OK &&
+              hipMemcpyAsync(c.c.host, c.c.dev, nbits, hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+              hipStreamSynchronize(c.stream) == hipSuccess;
+    if (!ok) {
+        printf("[HIP][sdrx_fm_demodulate] Error! %s\n", g_err);
+        return 0;
+    }
+    memcpy(out, c.c.host, nbits);
+    return nbits; // FM.h:147
+}
+
+extern "C" void sdrx_fm_modulate(double tx_rate, double mark, double space, const uint8_t *bits, size_t len,
+                                 double *out_real, size_t spb)
+{
+    // FM.h:44-74: two host cosine tables of spb samples and one memcpy per bit (2*spb cos calls in all).
+    if (!bits || !out_real || spb == 0) return;
+    const double PI = 3.141592653589793238460;
+    const double delta_t = 1.0 / tx_rate;
+    const double root_raised = sqrt(2) / sqrt(spb);
+    std::vector<double> w1(spb), w2(spb);
+    for (size_t i = 0; i < spb; i++) {
+        w1[i] = root_raised * cos(2.0 * PI * mark * delta_t * i);
+        w2[i] = root_raised * cos(2.0 * PI * space * delta_t * i);
+    }
+    for (size_t i = 0; i < len; i++) memcpy(&out_real[i * spb], bits[i] == 0 ? w2.data() : w1.data(), spb * sizeof(double));
+}
+
+// ---- FIR + demod chains on host buffers
+struct sdrx_chain {
+    int T = 0;
+    unsigned D = 1;
+    double *d_taps = nullptr;
+    double *d_state[2] = {nullptr, nullptr};
+    int cur = 0;
+    hipStream_t stream = nullptr;
+    Staging re, im, out;
+};
+
+extern "C" sdrx_chain_t *sdrx_chain_create(const double *taps, int num_taps, unsigned decim)
+{
+    if (!taps || num_taps <= 0 || decim == 0) return nullptr;
+    sdrx_chain *c = new sdrx_chain();
+    c->T = num_taps;
+    c->D = decim;
+    const size_t sd = sdrx_fir_state_doubles(num_taps);
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void **)&c->d_taps, num_taps * sizeof(double)) == hipSuccess &&
+              hipMemcpy(c->d_taps, taps, num_taps * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    for (int i = 0; ok && i < 2; i++)
+        ok = hipMalloc((void **)&c->d_state[i], sd * sizeof(double)) == hipSuccess &&
+             hipMemset(c->d_state[i], 0, sd * sizeof(double)) == hipSuccess;
+    if (!ok) {
+        set_error("sdrx_chain_create: device allocation failed");
+        sdrx_chain_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void sdrx_chain_destroy(sdrx_chain_t *c)
+{
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_taps) (void)hipFree(c->d_taps);
+    for (int i = 0; i < 2; i++)
+        if (c->d_state[i]) (void)hipFree(c->d_state[i]);
+    c->re.release();
+    c->im.release();
+    c->out.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void sdrx_chain_reset(sdrx_chain_t *c)
+{
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; i++) (void)hipMemset(c->d_state[i], 0, sdrx_fir_state_doubles(c->T) * sizeof(double));
+}
+
+static size_t chain_run(sdrx_chain *c, const double *re, const double *im, size_t n, void *out, size_t out_elem,
+                        FirEpilogue epi)
+{
+    if (!c || !re || !im || !out || n == 0) return 0;
+    const size_t bytes = n * sizeof(double), n_out = (n + c->D - 1) / c->D;
+    if (c->re.ensure(bytes) || c->im.ensure(bytes) || c->out.ensure(n_out * out_elem + 8)) return 0;
+    memcpy(c->re.host, re, bytes);
+    memcpy(c->im.host, im, bytes);
+    if (hipMemcpyAsync(c->re.dev, c->re.host, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(c->im.dev, c->im.host, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return 0;
+    sdrx_fir_job j;
+    memset(&j, 0, sizeof(j));
+    j.layout = SDRX_IQ_SPLIT;
+    j.in0 = c->re.dev;
+    j.in1 = c->im.dev;
+    j.n = n;
+    j.nchan = 1;
+    j.in_pitch = n;
+    j.taps = c->d_taps;
+    j.num_taps = c->T;
+    j.decim = c->D;
+    j.state_in = c->d_state[c->cur];
+    j.state_out = c->d_state[c->cur ^ 1];
+    j.state_pitch = sdrx_fir_state_doubles(c->T);
+    j.out0 = c->out.dev;
+    j.out_pitch = n_out;
+    j.stream = c->stream;
+    if (launch_fir(&j, epi) != SDRX_OK) return 0;
+    c->cur ^= 1;
+    if (hipMemcpyAsync(c->out.host, c->out.dev, n_out * out_elem, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return 0;
+    memcpy(out, c->out.host, n_out * out_elem);
+    return n_out;
+}
+
+extern "C" size_t sdrx_chain_fir_am(sdrx_chain_t *c, const double *re, const double *im, size_t n, uint8_t *bits)
+{
+    return chain_run(c, re, im, n, bits, 1, EPI_AM);
+}
+
+extern "C" size_t sdrx_chain_fir_fmdisc(sdrx_chain_t *c, const double *re, const double *im, size_t n, double *angle)
+{
+    return chain_run(c, re, im, n, angle, sizeof(double), EPI_DISC);
+}
+
+// ---- PSK objects
+struct sdrx_psk {
+    int kind = 0;
+    sdrx_psk_state *d_state = nullptr;
+    hipStream_t stream = nullptr;
+    Staging in, mid, out, hits;
+};
+
+extern "C" sdrx_psk_t *sdrx_psk_create(int kind, uint64_t bpsk_uw, const double *qpsk_uw64, size_t uw_len)
+{
+    if (kind != SDRX_BPSK && kind != SDRX_QPSK) return nullptr;
+    sdrx_psk *p = new sdrx_psk();
+    p->kind = kind;
+    sdrx_psk_state st;
+    if (kind == SDRX_BPSK) sdrx_psk_state_init_bpsk(&st, bpsk_uw, uw_len);
+    else sdrx_psk_state_init_qpsk(&st, qpsk_uw64, uw_len);
+    bool ok = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void **)&p->d_state, sizeof(st)) == hipSuccess &&
+              hipMemcpy(p->d_state, &st, sizeof(st), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        set_error("sdrx_psk_create: device allocation failed");
+        sdrx_psk_destroy(p);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void sdrx_psk_destroy(sdrx_psk_t *p)
+{
+    if (!p) return;
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->d_state) (void)hipFree(p->d_state);
+    p->in.release();
+    p->mid.release();
+    p->out.release();
+    p->hits.release();
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+extern "C" void sdrx_psk_get_state(sdrx_psk_t *p, sdrx_psk_state *out)
+{
+    if (!p || !out) return;
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipMemcpy(out, p->d_state, sizeof(*out), hipMemcpyDeviceToHost);
+}
+
+extern "C" void sdrx_psk_set_state(sdrx_psk_t *p, const sdrx_psk_state *in)
+{
+    if (!p || !in) return;
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipMemcpy(p->d_state, in, sizeof(*in), hipMemcpyHostToDevice);
+}
+
+static const size_t PSK_MAX_HITS = 4096;
+
+static size_t psk_fetch_hits(sdrx_psk *p, uint64_t *hits, size_t max_hits)
+{
+    sdrx_psk_state st;
+    if (hipMemcpy(&st, p->d_state, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    size_t nh = (size_t)st.n_hits;
+    if (hits && max_hits) {
+        size_t k = nh < max_hits ? nh : max_hits;
+        if (k > PSK_MAX_HITS) k = PSK_MAX_HITS;
+        memcpy(hits, p->hits.host, k * sizeof(uint64_t));
+    }
+    return nh;
+}
+
+extern "C" size_t sdrx_psk_demodulate(sdrx_psk_t *p, const double *iq, size_t n, double *out, uint64_t *hits,
+                                      size_t max_hits)
+{
+    if (!p || !iq || !out) return 0;
+    const size_t m = n / 4, nd = (m + 1) / 2; // decode: n/4 (BPSK.cpp:299); decimate by 2: ceil (Resample.h:51)
+    if (m == 0) return 0;
+    const size_t in_bytes = n * 2 * sizeof(double);
+    if (p->in.ensure(in_bytes) || p->mid.ensure(sdrx_psk_work_bytes(n, 1)) || p->out.ensure(nd + 8) ||
+        p->hits.ensure(PSK_MAX_HITS * sizeof(uint64_t)))
+        return 0;
+    memcpy(p->in.host, iq, in_bytes);
+    if (hipMemcpyAsync(p->in.dev, p->in.host, in_bytes, hipMemcpyHostToDevice, p->stream) != hipSuccess) return 0;
+    unsigned char *w = (unsigned char *)p->mid.dev;
+    double *mf = (double *)w;
+    double *zst = (double *)(w + align256(m * 2 * sizeof(double)));
+    double *dst = (double *)((unsigned char *)zst + align256(MF_STATE * sizeof(double)));
+    if (mf_launch((double *)p->in.dev, n, 1, n, mf, m, zst, dst, p->stream) != SDRX_OK) return 0;
+    if (launch_psk_loops(p->kind, mf, m, 1, m, p->d_state, (uint8_t *)p->out.dev, nd, 1, 1, p->stream) != SDRX_OK)
+        return 0;
+    if (launch_psk_ambiguity_hits(p->kind, (uint8_t *)p->out.dev, nd, 1, nd, p->d_state,
+                                  (unsigned long long *)p->hits.dev, PSK_MAX_HITS, p->stream) != SDRX_OK)
+        return 0;
+    if (hipMemcpyAsync(p->out.host, p->out.dev, nd, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+        hipMemcpyAsync(p->hits.host, p->hits.dev, PSK_MAX_HITS * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream) !=
+            hipSuccess ||
+        hipStreamSynchronize(p->stream) != hipSuccess)
+        return 0;
+    const uint8_t *d = (const uint8_t *)p->out.host;
+    for (size_t i = 0; i < nd; i++) out[i] = (double)d[i]; // output block real part: BPSK.cpp:167-172
+    (void)psk_fetch_hits(p, hits, max_hits);
+    return nd;
+}
+
+extern "C" size_t sdrx_psk_decode_pulse_shape(sdrx_psk_t *p, const double *iq, size_t n, double *re, double *im)
+{
+    if (!p || !iq || !re || !im) return 0;
+    const size_t m = n / 4;
+    if (m == 0) return 0;
+    const size_t in_bytes = n * 2 * sizeof(double);
+    if (p->in.ensure(in_bytes) || p->mid.ensure(sdrx_psk_work_bytes(n, 1))) return 0;
+    memcpy(p->in.host, iq, in_bytes);
+    if (hipMemcpyAsync(p->in.dev, p->in.host, in_bytes, hipMemcpyHostToDevice, p->stream) != hipSuccess) return 0;
+    unsigned char *w = (unsigned char *)p->mid.dev;
+    double *mf = (double *)w;
+    double *zst = (double *)(w + align256(m * 2 * sizeof(double)));
+    double *dst = (double *)((unsigned char *)zst + align256(MF_STATE * sizeof(double)));
+    if (mf_launch((double *)p->in.dev, n, 1, n, mf, m, zst, dst, p->stream) != SDRX_OK) return 0;
+    if (hipMemcpyAsync(p->mid.host, mf, m * 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+        hipStreamSynchronize(p->stream) != hipSuccess)
+        return 0;
+    const double *h = (const double *)p->mid.host;
+    for (size_t i = 0; i < m; i++) { re[i] = h[2 * i]; im[i] = h[2 * i + 1]; }
+    return m;
+}
+
+static int psk_stage_loops(sdrx_psk *p, double *re, double *im, size_t n, int timing, int phase)
+{
+    const size_t bytes = n * 2 * sizeof(double), nd = (n + 1) / 2;
+    if (p->mid.ensure(bytes) || p->out.ensure(nd + 8)) return SDRX_ENOMEM;
+    double *h = (double *)p->mid.host;
+    for (size_t i = 0; i < n; i++) { h[2 * i] = re[i]; h[2 * i + 1] = im[i]; }
+    SDRX_HIP(hipMemcpyAsync(p->mid.dev, p->mid.host, bytes, hipMemcpyHostToDevice, p->stream));
+    int rc = launch_psk_loops(p->kind, (double *)p->mid.dev, n, 1, n, p->d_state, (uint8_t *)p->out.dev, nd, timing,
+                              phase, p->stream);
+    if (rc) return rc;
+    if (timing) SDRX_HIP(hipMemcpyAsync(p->mid.host, p->mid.dev, bytes, hipMemcpyDeviceToHost, p->stream));
+    if (phase) SDRX_HIP(hipMemcpyAsync(p->out.host, p->out.dev, nd, hipMemcpyDeviceToHost, p->stream));
+    SDRX_HIP(hipStreamSynchronize(p->stream));
+    return SDRX_OK;
+}
+
+extern "C" void sdrx_psk_timing(sdrx_psk_t *p, double *re, double *im, size_t n)
+{
+    if (!p || !re || !im || n == 0) return;
+    if (psk_stage_loops(p, re, im, n, 1, 0) != SDRX_OK) return;
+    const double *h = (const double *)p->mid.host;
+    for (size_t i = 0; i < n; i++) { re[i] = h[2 * i]; im[i] = h[2 * i + 1]; }
+}
+
+extern "C" size_t sdrx_psk_phase_correction(sdrx_psk_t *p, double *re, double *im, size_t n)
+{
+    if (!p || !re || !im || n == 0) return 0;
+    if (psk_stage_loops(p, re, im, n, 0, 1) != SDRX_OK) return 0;
+    const size_t nd = (n + 1) / 2;
+    const uint8_t *d = (const uint8_t *)p->out.host;
+    for (size_t i = 0; i < nd; i++) re[i] = (double)d[i];
+    if (nd < n) re[nd] = 0.0;                    // decimate's tail clear touches only block[dst]: Resample.h:46-49
+    for (size_t i = 0; i < n; i++) im[i] = 0.0; // BPSK.cpp:410
+    return nd;
+}
+
+extern "C" size_t sdrx_psk_ambiguity(sdrx_psk_t *p, double *re, size_t n, uint64_t *hits, size_t max_hits)
+{
+    if (!p || !re || n == 0) return 0;
+    if (p->out.ensure(n + 8) || p->hits.ensure(PSK_MAX_HITS * sizeof(uint64_t))) return 0;
+    uint8_t *h = (uint8_t *)p->out.host;
+    for (size_t i = 0; i < n; i++) h[i] = (uint8_t)(int)re[i];
+    if (hipMemcpyAsync(p->out.dev, p->out.host, n, hipMemcpyHostToDevice, p->stream) != hipSuccess) return 0;
+    if (launch_psk_ambiguity_hits(p->kind, (uint8_t *)p->out.dev, n, 1, n, p->d_state,
+                                  (unsigned long long *)p->hits.dev, PSK_MAX_HITS, p->stream) != SDRX_OK)
+        return 0;
+    if (hipMemcpyAsync(p->out.host, p->out.dev, n, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+        hipMemcpyAsync(p->hits.host, p->hits.dev, PSK_MAX_HITS * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream) !=
+            hipSuccess ||
+        hipStreamSynchronize(p->stream) != hipSuccess)
+        return 0;
+    for (size_t i = 0; i < n; i++) re[i] = (double)h[i];
+    return psk_fetch_hits(p, hits, max_hits);
+}
+
+extern "C" int sdrx_psk_modulate(int kind, const uint8_t *sym, size_t len, double *out_real, double *out_imag,
+                                 size_t len_mod)
+{
+    if (!sym || !out_real || (kind == SDRX_QPSK && !out_imag)) return SDRX_EINVAL;
+    // size checks print and return like the reference: BPSK.cpp:125-129, QPSK.cpp:158-162
+    if (kind == SDRX_BPSK && len_mod < 8 * len) {
+        printf("ERROR:: QPSK modulation output arrays are not large enough!!! [%zu vs %zu\n", len_mod, 8 * len);
+        return SDRX_OK;
+    }
+    if (kind == SDRX_QPSK && len_mod != 8 * len) {
+        printf("ERROR:: QPSK modulation output arrays are not large enough!!!\n");
+        return SDRX_OK;
+    }
+    if (len == 0) return SDRX_OK;
+    HostCtx &c = t_ctx;
+    const size_t n = 8 * len, bytes = n * sizeof(double);
+    int rc = c.ready();
+    if (rc || (rc = c.a.ensure(bytes)) || (rc = c.b.ensure(bytes)) || (rc = c.c.ensure(len + 8))) return rc;
+    memcpy(c.a.host, out_real, bytes); // prior contents take part beyond the byte-count memset (BPSK.cpp:131)
+    if (kind == SDRX_QPSK) memcpy(c.b.host, out_imag, bytes);
+    memcpy(c.c.host, sym, len);
+    SDRX_HIP(hipMemcpyAsync(c.a.dev, c.a.host, bytes, hipMemcpyHostToDevice, c.stream));
+    if (kind == SDRX_QPSK) SDRX_HIP(hipMemcpyAsync(c.b.dev, c.b.host, bytes, hipMemcpyHostToDevice, c.stream));
+    SDRX_HIP(hipMemcpyAsync(c.c.dev, c.c.host, len, hipMemcpyHostToDevice, c.stream));
+    rc = launch_psk_modulate(kind, (const uint8_t *)c.c.dev, len, (double *)c.a.dev,
+                             kind == SDRX_QPSK ? (double *)c.b.dev : nullptr, len_mod / 8, c.stream);
+    if (rc) return rc;
+    SDRX_HIP(hipMemcpyAsync(c.a.host, c.a.dev, bytes, hipMemcpyDeviceToHost, c.stream));
+    if (kind == SDRX_QPSK) SDRX_HIP(hipMemcpyAsync(c.b.host, c.b.dev, bytes, hipMemcpyDeviceToHost, c.stream));
+    SDRX_HIP(hipStreamSynchronize(c.stream));
+    memcpy(out_real, c.a.host, bytes);
+    if (kind == SDRX_QPSK) memcpy(out_imag, c.b.host, bytes);
+    return SDRX_OK;
+}
+
+// =========================================================================== 3. legacy layer
+
+namespace {
+struct Radio {
+    hipStream_t stream = nullptr;
+    void *h_re = nullptr, *h_im = nullptr, *h_out = nullptr; // pinned
+    double *d_re = nullptr, *d_im = nullptr;
+    uint8_t *d_out = nullptr;
+    double *d_w1 = nullptr, *d_w2 = nullptr; // FM only
+    size_t cap = 0;
+};
+std::vector<Radio> g_am, g_fm;
+double g_fm_mark = 19000, g_fm_space = 20000;
+size_t g_fm_rate = 0, g_fm_spb = 0;
+
+bool radio_alloc(Radio &r, size_t max_points)
+{
+    r.cap = max_points;
+    return hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) == hipSuccess &&
+           hipHostMalloc(&r.h_re, max_points * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+           hipHostMalloc(&r.h_im, max_points * sizeof(double), hipHostMallocDefault) == hipSuccess &&
+           hipHostMalloc(&r.h_out, max_points + 8, hipHostMallocDefault) == hipSuccess &&
+           hipMalloc((void **)&r.d_re, max_points * sizeof(double)) == hipSuccess &&
+           hipMalloc((void **)&r.d_im, max_points * sizeof(double)) == hipSuccess &&
+           hipMalloc((void **)&r.d_out, max_points + 8) == hipSuccess;
+}
+
+void radio_free(Radio &r)
+{
+    if (r.stream) (void)hipStreamSynchronize(r.stream);
+    if (r.h_re) (void)hipHostFree(r.h_re);
+    if (r.h_im) (void)hipHostFree(r.h_im);
+    if (r.h_out) (void)hipHostFree(r.h_out);
+    if (r.d_re) (void)hipFree(r.d_re);
+    if (r.d_im) (void)hipFree(r.d_im);
+    if (r.d_out) (void)hipFree(r.d_out);
+    if (r.d_w1) (void)hipFree(r.d_w1);
+    if (r.d_w2) (void)hipFree(r.d_w2);
+    if (r.stream) (void)hipStreamDestroy(r.stream);
+    r = Radio();
+}
+
+bool fm_upload_waves(size_t spb, size_t rate)
+{
+    std::vector<double> w1, w2;
+    fm_waves((double)rate, g_fm_mark, g_fm_space, spb, w1, w2); // fm.cu:62-68
+    for (Radio &r : g_fm) {
+        (void)hipStreamSynchronize(r.stream);
+        if (r.d_w1) (void)hipFree(r.d_w1);
+        if (r.d_w2) (void)hipFree(r.d_w2);
+        r.d_w1 = r.d_w2 = nullptr;
+        if (hipMalloc((void **)&r.d_w1, (spb ? spb : 1) * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&r.d_w2, (spb ? spb : 1) * sizeof(double)) != hipSuccess ||
+            hipMemcpy(r.d_w1, w1.data(), spb * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(r.d_w2, w2.data(), spb * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+            return false;
+    }
+    g_fm_spb = spb;
+    g_fm_rate = rate;
+    return true;
+}
+} // namespace
+
+extern "C" void am_gpu_initialize(size_t MAX_NUM_POINTS, size_t num_of_radios)
+{
+    g_am.resize(num_of_radios);
+    for (Radio &r : g_am)
+        if (!radio_alloc(r, MAX_NUM_POINTS)) printf("[HIP][am_gpu_initialize] Error!\n");
+}
+
+extern "C" void am_gpu_free(void)
+{
+    for (Radio &r : g_am) radio_free(r);
+    g_am.clear();
+}
+
+extern "C" double am_gpu_demodulation(int RADIO_ID, double *real, double *imag, uint8_t *output,
+                                      size_t number_of_points, size_t ds)
+{
+    using clk = std::chrono::high_resolution_clock;
+    if (RADIO_ID < 0 || (size_t)RADIO_ID >= g_am.size() || number_of_points > g_am[RADIO_ID].cap || ds == 0) {
+        printf("[HIP][am_gpu_demodulation] Error!\n");
+        return 0.0;
+    }
+    Radio &r = g_am[RADIO_ID];
+    const size_t bytes = number_of_points * sizeof(double);
+    memcpy(r.h_re, real, bytes);
+    memcpy(r.h_im, imag, bytes);
+    bool ok = hipMemcpyAsync(r.d_re, r.h_re, bytes, hipMemcpyHostToDevice, r.stream) == hipSuccess &&
+              hipMemcpyAsync(r.d_im, r.h_im, bytes, hipMemcpyHostToDevice, r.stream) == hipSuccess &&
+              hipStreamSynchronize(r.stream) == hipSuccess;
+    clk::time_point t1 = clk::now(); // kernel wall seconds, as am.cu:130-136
+    ok = ok && launch_am_demod(r.d_re, r.d_im, r.d_out, number_of_points, ds, r.stream) == SDRX_OK &&
+         hipStreamSynchronize(r.stream) == hipSuccess;
+    clk::time_point t2 = clk::now();
+    const size_t nout = number_of_points / ds; // am.cu:140 pulls back number_of_points/ds bytes
+    ok = ok && hipMemcpyAsync(r.h_out, r.d_out, nout, hipMemcpyDeviceToHost, r.stream) == hipSuccess &&
+         hipStreamSynchronize(r.stream) == hipSuccess;
+    if (!ok) printf("[HIP][am_gpu_demodulation] Error!\n"); // am.cu:143-146
+    else memcpy(output, r.h_out, nout);
+    return std::chrono::duration_cast<std::chrono::duration<double>>(t2 - t1).count();
+}
+
+extern "C" void fm_gpu_initialize(size_t num_of_radios, size_t MaxBufferSize, size_t rx_sample_rate,
+                                  size_t samples_per_bit, double MARK_FREQ, double SPACE_FREQ)
+{
+    g_fm.resize(num_of_radios);
+    g_fm_mark = MARK_FREQ;
+    g_fm_space = SPACE_FREQ;
+    bool ok = true;
+    for (Radio &r : g_fm) ok = radio_alloc(r, MaxBufferSize) && ok;
+    ok = ok && fm_upload_waves(samples_per_bit, rx_sample_rate);
+    if (!ok) printf("[HIP][fm_gpu_initialize] Error!\n");
+}
+
+extern "C" void fm_gpu_free(void)
+{
+    for (Radio &r : g_fm) radio_free(r);
+    g_fm.clear();
+}
+
+extern "C" void fm_gpu_set_samples_per_bit(size_t samples_per_bit, size_t rx_sample_rate)
+{
+    // The receiver declares and calls this with ONE argument (rtlsdr_receiver.cpp:103,1720), so the
+    // second may be garbage: anything that is not a plausible rate falls back to the init-time rate.
+    size_t rate = (rx_sample_rate == 0 || rx_sample_rate > 1000000000000ULL) ? g_fm_rate : rx_sample_rate;
+    if (!fm_upload_waves(samples_per_bit, rate)) printf("[HIP][fm_gpu_set_samples_per_bit] Error!\n");
+}
+
+extern "C" double fm_gpu_demodulation(int RADIO_ID, double *real, double *imag, uint8_t *output,
+                                      size_t number_of_points, size_t ds)
+{
+    using clk = std::chrono::high_resolution_clock;
+    (void)imag; // FM<T>::demodulate reads the real rail only (FM.h:134-135)
+    if (RADIO_ID < 0 || (size_t)RADIO_ID >= g_fm.size() || number_of_points > g_fm[RADIO_ID].cap || ds == 0) {
+        printf("[HIP][fm_gpu_demodulation] Error!\n");
+        return 0.0;
+    }
+    if (ds != g_fm_spb && !fm_upload_waves(ds, g_fm_rate)) { // kernel is launched with WaveSize = ds (fm.cu:149)
+        printf("[HIP][fm_gpu_demodulation] Error!\n");
+        return 0.0;
+    }
+    Radio &r = g_fm[RADIO_ID];
+    const size_t bytes = number_of_points * sizeof(double);
+    memcpy(r.h_re, real, bytes);
+    bool ok = hipMemcpyAsync(r.d_re, r.h_re, bytes, hipMemcpyHostToDevice, r.stream) == hipSuccess &&
+              hipStreamSynchronize(r.stream) == hipSuccess;
+    clk::time_point t1 = clk::now();
+    ok = ok && launch_fm_demod(r.d_re, r.d_w1, r.d_w2, r.d_out, number_of_points, ds, r.stream) == SDRX_OK &&
+         hipStreamSynchronize(r.stream) == hipSuccess;
+    clk::time_point t2 = clk::now();
+    const size_t nout = number_of_points / ds;
+    ok = ok && hipMemcpyAsync(r.h_out, r.d_out, nout, hipMemcpyDeviceToHost, r.stream) == hipSuccess &&
+         hipStreamSynchronize(r.stream) == hipSuccess;
+    if (!ok) printf("[HIP][fm_gpu_demodulation] Error!\n"); // fm.cu:159-162
+    else memcpy(output, r.h_out, nout);
+    return std::chrono::duration_cast<std::chrono::duration<double>>(t2 - t1).count();
+}
+
+extern "C" int32_t ones_zeros_demodulation(double *real, double *imag, size_t number_of_points)
+{
+    HostCtx &c = t_ctx;
+    const size_t bytes = number_of_points * sizeof(double);
+    if (number_of_points == 0) return 0;
+    if (c.ready() || c.a.ensure(bytes) || c.b.ensure(bytes) || c.c.ensure(64)) {
+        printf("[HIP][ones_zeros_demodulation] Error!\n");
+        return 0;
+    }
+    memcpy(c.a.host, real, bytes);
+    memcpy(c.b.host, imag, bytes);
+    bool ok = hipMemcpyAsync(c.a.dev, c.a.host, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              hipMemcpyAsync(c.b.dev, c.b.host, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              launch_ones_zeros((double *)c.a.dev, (double *)c.b.dev, number_of_points, (int32_t *)c.c.dev,
+                                c.stream) == SDRX_OK &&
+              hipMemcpyAsync(c.c.host, c.c.dev, sizeof(int32_t), hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+              hipStreamSynchronize(c.stream) == hipSuccess;
+    if (!ok) {
+        printf("[HIP][ones_zeros_demodulation] Error!\n"); // ones_zeros.cu:46-49
+        return 0;
+    }
+    return *(int32_t *)c.c.host;
+}

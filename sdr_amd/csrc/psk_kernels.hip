@@ -1,0 +1,413 @@
+// psk_kernels.hip -- BPSK / QPSK loops, unique-word ambiguity pass and pulse shaper for gfx950.
+//
+//   psk_loops_kernel     : symbol_timing_synchronization (BPSK.cpp:302-389 / QPSK.cpp:264-351) and
+//                          phase_shift_correction + decimate-by-2 (BPSK.cpp:393-444 / QPSK.cpp:355-414)
+//   psk_ambiguity_kernel : phase_ambiguity_correction (BPSK.cpp:446-487 / QPSK.cpp:416-509)
+//   psk_modulate_kernel  : encode_LUT + upsample_fill_w_zeros + encode_pulseShape
+//                          (BPSK.cpp:112-146 / QPSK.cpp:144-188, Resample.cpp:24-36)
+// The matched filter (decode_pulseShape) is the generic FIR tile kernel of fir_kernels.hip.
+//
+// The two loops are sample-recursive with sign / floor / compare nonlinearities, so they cannot be
+// tiled in time without changing results.  They run one CHANNEL per lane with the whole loop state
+// in registers and exactly the reference's operation order (no FMA contraction); throughput comes
+// from the number of independent channels.  cos/sin are include/sdrx_math.h on both sides.
+#include "sdrx_internal.h"
+
+#include "../../include/sdrx_math.h"
+
+namespace sdrx {
+
+const double RRC_COEFF[129] = { // MATLAB rcosine(1/8,1,'sqrt',0.5,8): values of BPSK.cpp:18-50 / QPSK.cpp:32-64
+    -0.000882663055055987, -0.000746201590523265, -0.000336789968798916, 0.000225038893553655,
+    0.000757880681389978,  0.001077943504359050,  0.001062303725777150,  0.000695521249813576,
+    8.24465490986367e-05,  -0.000579554041955506, -0.001062303725777150, -0.001183702054816000,
+    -0.000874477709296126, -0.000211083163638599, 0.000599193283619645,  0.001279536876191750,
+    0.001573979573701230,  0.001338143762729140,  0.000599193283619642,  -0.000438236415412023,
+    -0.001446863119017230, -0.002078893324143190, -0.002084671221261930, -0.001408617284422990,
+    -0.000227352605090172, 0.001088699270085450,  0.002084671221261940,  0.002371289907799650,
+    0.001768388256576610,  0.000391988582678128,  -0.001351122110122730, -0.002869993360503870,
+    -0.003572683794274230, -0.003072685906611650, -0.001351122110122720, 0.001186107048403510,
+    0.003789403406949890,  0.005575980755162950,  0.005816670050933640,  0.004213278581633850,
+    0.001071805138282270,  -0.002702696087965530, -0.005816670050933650, -0.006968745846090550,
+    -0.005305164769729840, -0.000815536975401244, 0.005468827588591990,  0.011573823048484000,
+    0.015005271935951800,  0.013430574641186900,  0.005468827588591980,  -0.008615615450369140,
+    -0.026525823848649200, -0.044008760276746200, -0.055452254485567400, -0.054931750238658300,
+    -0.037513179839879400, -0.000532386899804849, 0.055452254485567400,  0.126288206185736000,
+    0.204577471545948000,  0.280728910881642000,  0.344536138081295000,  0.386975375596443000,
+    0.401855774335913000,  0.386975375596443000,  0.344536138081295000,  0.280728910881642000,
+    0.204577471545948000,  0.126288206185736000,  0.055452254485567400,  -0.000532386899804849,
+    -0.037513179839879400, -0.054931750238658300, -0.055452254485567400, -0.044008760276746200,
+    -0.026525823848649200, -0.008615615450369140, 0.005468827588591980,  0.013430574641186900,
+    0.015005271935951800,  0.011573823048484000,  0.005468827588591990,  -0.000815536975401244,
+    -0.005305164769729840, -0.006968745846090550, -0.005816670050933650, -0.002702696087965530,
+    0.001071805138282270,  0.004213278581633850,  0.005816670050933640,  0.005575980755162950,
+    0.003789403406949890,  0.001186107048403510,  -0.001351122110122720, -0.003072685906611650,
+    -0.003572683794274230, -0.002869993360503870, -0.001351122110122730, 0.000391988582678128,
+    0.001768388256576610,  0.002371289907799650,  0.002084671221261940,  0.001088699270085450,
+    -0.000227352605090172, -0.001408617284422990, -0.002084671221261930, -0.002078893324143190,
+    -0.001446863119017230, -0.000438236415412023, 0.000599193283619642,  0.001338143762729140,
+    0.001573979573701230,  0.001279536876191750,  0.000599193283619645,  -0.000211083163638599,
+    -0.000874477709296126, -0.001183702054816000, -0.001062303725777150, -0.000579554041955506,
+    8.24465490986367e-05,  0.000695521249813576,  0.001062303725777150,  0.001077943504359050,
+    0.000757880681389978,  0.000225038893553655,  -0.000336789968798916, -0.000746201590523265,
+    -0.000882663055055987};
+
+#define SDRX_SGN(v) (((v) == 0.0) ? 0.0 : (((v) < 0.0) ? -1.0 : 1.0)) /* BPSK.h:16 */
+
+// ------------------------------------------------------------------------------------- loops
+
+struct Interp {
+    double d1, d2, d3, d4, d5;
+};
+
+__device__ __forceinline__ double interp_filter(Interp &d, double in, double mu)
+{
+    const double K = -0.5; // BPSK.cpp:319-344
+    double V1 = d.d1 - K * in;
+    double V2 = V1 + d.d2;
+    double V3 = V2 - d.d3;
+    double V4 = K * in - d.d1 + d.d4;
+    double V5 = V4 + d.d2;
+    double V6 = d.d3 + V5;
+    double V7 = V3 * mu + V6;
+    double V8 = d.d5 + mu * V7;
+    d.d3 = d.d2;
+    d.d2 = d.d1;
+    d.d1 = K * in;
+    d.d5 = d.d4;
+    d.d4 = in;
+    return V8;
+}
+
+__global__ void __launch_bounds__(64) psk_loops_kernel(int kind, double2 *__restrict__ mf, size_t m, size_t nchan,
+                                                       size_t pitch, sdrx_psk_state *__restrict__ states,
+                                                       uint8_t *__restrict__ dec, size_t out_pitch, int run_timing,
+                                                       int run_phase)
+{
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchan) return;
+    sdrx_psk_state *st = states + c;
+    double nco = st->nco_delay, reg_mu = st->reg_mu, reg_Q = st->reg_Q, reg_I = st->reg_I, mu_delay = st->mu_delay;
+    Interp iq = {st->iq_d[0], st->iq_d[1], st->iq_d[2], st->iq_d[3], st->iq_d[4]};
+    Interp ii = {st->ii_d[0], st->ii_d[1], st->ii_d[2], st->ii_d[3], st->ii_d[4]};
+    double g1 = st->g1, g2 = st->g2, g3 = st->g3, g4 = st->g4;
+    double lf_x = st->lf_x, lf_y = st->lf_y;
+    double dds_delay = st->dds_delay, plf_x = st->plf_x, plf_y = st->plf_y;
+    double tr = 0.0, ti = 0.0, temp = 0.0; // locals of phase_shift_correction: restart at 0 every call
+
+    double2 *x = mf + c * pitch;
+    uint8_t *d = dec ? dec + c * out_pitch : nullptr;
+
+    constexpr int PF = 4; // samples fetched ahead per lane: one 64-byte line
+    double2 nxt[PF];
+#pragma unroll
+    for (int k = 0; k < PF; k++) nxt[k] = ((size_t)k < m) ? x[k] : make_double2(0.0, 0.0);
+
+    for (size_t i0 = 0; i0 < m; i0 += PF) {
+        double2 cur[PF];
+#pragma unroll
+        for (int k = 0; k < PF; k++) cur[k] = nxt[k];
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            size_t ii2 = i0 + PF + k;
+            nxt[k] = (ii2 < m) ? x[ii2] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const size_t i = i0 + k;
+            if (i >= m) break;
+            double re = cur[k].x, im = cur[k].y;
+            if (run_timing) { // BPSK.cpp:307-316
+                const double strobe = (nco < 0) ? 1.0 : 0.0;
+                if (strobe >= 1) reg_mu = mu_delay * 2;
+                const double mu = reg_mu;
+                const double Q = interp_filter(iq, re, mu); // "Q" is fed the real rail (BPSK.cpp:311)
+                const double I = interp_filter(ii, im, mu);
+                double e = 0; // GardnerDetector, BPSK.cpp:346-363
+                if (strobe >= 0.5) e = (g3 * (-SDRX_SGN(Q) + SDRX_SGN(g4)) + (g1 * (-SDRX_SGN(I) + SDRX_SGN(g2))));
+                g2 = g1;
+                g1 = I;
+                g4 = g3;
+                g3 = Q;
+                const double K1 = -0.00587880145347487, K2 = -2.35152058138995e-05; // LoopFilter, BPSK.cpp:365-373
+                const double v = lf_y + K2 * e + K1 * (e - lf_x);
+                lf_x = e;
+                lf_y = v;
+                const double eta = nco - floor(nco); // NcoControl, BPSK.cpp:375-380
+                nco = eta - 0.5 - v;
+                mu_delay = eta;
+                if (strobe >= 1) { reg_Q = Q; reg_I = I; }
+                re = reg_Q;
+                im = reg_I;
+                if (!run_phase) x[i] = make_double2(re, im);
+            }
+            if (run_phase) {
+                const double PK1 = 0.0620001240002480, PK2 = 0.000992001984003968; // BPSK.cpp:424-432
+                double sn, cs;
+                int decision;
+                if (kind == SDRX_BPSK) { // BPSK.cpp:399-411
+                    sdrx_sincos(dds_delay + temp, &sn, &cs);
+                    dds_delay = dds_delay + temp;
+                    tr = re * cs - im * sn;
+                    ti = im * cs + re * sn;
+                    const double val = 8.0 * (SDRX_SGN(ti) * tr - SDRX_SGN(tr) * ti);
+                    temp = plf_y - PK1 * plf_x + (PK1 + PK2) * val;
+                    plf_x = val;
+                    plf_y = temp;
+                    decision = (SDRX_SGN(tr) < 0) ? 1 : 0;
+                } else { // QPSK.cpp:361-373: loop filter first, from the previous product
+                    const double val = 8.0 * (SDRX_SGN(ti) * tr - SDRX_SGN(tr) * ti);
+                    temp = plf_y - PK1 * plf_x + (PK1 + PK2) * val;
+                    plf_x = val;
+                    plf_y = temp;
+                    sdrx_sincos(dds_delay + temp, &sn, &cs);
+                    dds_delay = dds_delay + temp;
+                    tr = re * cs - im * sn;
+                    ti = im * cs + re * sn;
+                    const double sr = SDRX_SGN(tr), si = SDRX_SGN(ti); // QPSK.cpp:396-414
+                    if (sr < 0 && si < 0) decision = 3;
+                    else if (sr > 0 && si < 0) decision = 2;
+                    else if (sr < 0 && si > 0) decision = 1;
+                    else decision = 0;
+                }
+                if ((i & 1) == 0 && d) d[i >> 1] = (uint8_t)decision; // decimate(real, n, 2): keeps 0,2,4,...
+            }
+        }
+    }
+    if (run_timing) {
+        st->nco_delay = nco; st->reg_mu = reg_mu; st->reg_Q = reg_Q; st->reg_I = reg_I; st->mu_delay = mu_delay;
+        st->iq_d[0] = iq.d1; st->iq_d[1] = iq.d2; st->iq_d[2] = iq.d3; st->iq_d[3] = iq.d4; st->iq_d[4] = iq.d5;
+        st->ii_d[0] = ii.d1; st->ii_d[1] = ii.d2; st->ii_d[2] = ii.d3; st->ii_d[3] = ii.d4; st->ii_d[4] = ii.d5;
+        st->g1 = g1; st->g2 = g2; st->g3 = g3; st->g4 = g4;
+        st->lf_x = lf_x; st->lf_y = lf_y;
+    }
+    if (run_phase) {
+        st->dds_delay = dds_delay; st->plf_x = plf_x; st->plf_y = plf_y;
+    }
+}
+
+int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch, sdrx_psk_state *states,
+                     uint8_t *decisions, size_t out_pitch, int run_timing, int run_phase, hipStream_t s)
+{
+    if (!mf_iq || !states || (run_phase && !decisions) || (kind != SDRX_BPSK && kind != SDRX_QPSK)) {
+        set_error("psk_loops: bad argument");
+        return SDRX_EINVAL;
+    }
+    if (nchan == 0 || m == 0) return SDRX_OK;
+    size_t blocks = (nchan + 63) / 64;
+    if (blocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
+    hipLaunchKernelGGL(psk_loops_kernel, dim3((unsigned)blocks), dim3(64), 0, s, kind, (double2 *)mf_iq, m, nchan,
+                       mf_pitch, states, decisions, out_pitch, run_timing, run_phase);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+// --------------------------------------------------------------------------------- ambiguity
+//
+// One workgroup per channel.  Positions are tested 256 at a time; hits are rare and must update
+// the saturating confidence counters in stream order (confidence_counter.cpp:41-61 is not
+// commutative at the rails), so lane 0 folds a chunk's hits sequentially, only for chunks that
+// have any.
+__global__ void __launch_bounds__(256) psk_ambiguity_kernel(int kind, uint8_t *__restrict__ dec, size_t m,
+                                                            size_t out_pitch, sdrx_psk_state *__restrict__ states,
+                                                            unsigned long long *__restrict__ hits, size_t max_hits)
+{
+    __shared__ uint8_t uwc[4][64];
+    __shared__ signed char ev[256];
+    __shared__ int s_cc[4];
+    __shared__ int s_lut, s_nh;
+    const unsigned tid = threadIdx.x;
+    const size_t c = blockIdx.x;
+    sdrx_psk_state *st = states + c;
+    uint8_t *d = dec + c * out_pitch;
+    const int U = st->uw_size > 64 ? 64 : (st->uw_size < 0 ? 0 : st->uw_size);
+    if (tid < 64 && (int)tid < U) {
+        const int idx = (kind == SDRX_BPSK) ? (U - 1 - (int)tid) : (63 - (int)tid); // BPSK.cpp:456, QPSK.cpp:428
+        for (int k = 0; k < 4; k++) uwc[k][tid] = (uint8_t)st->uw[k][idx];
+    }
+    if (tid < 4) s_cc[tid] = st->cc[tid];
+    if (tid == 0) s_nh = 0;
+    __syncthreads();
+    if (m >= (size_t)U) {
+        const size_t npos = m - (size_t)U; // i < num_of_points - UW_SIZE
+        for (size_t base = 0; base < npos; base += 256) {
+            const size_t i = base + tid;
+            int code = -1;
+            if (i < npos) {
+                if (kind == SDRX_BPSK) {
+                    bool m0 = true, m180 = true;
+                    for (int j = 0; j < U && (m0 || m180); j++) {
+                        uint8_t v = d[i + j];
+                        m0 = m0 && (v == uwc[0][j]);
+                        m180 = m180 && (v == uwc[1][j]);
+                    }
+                    code = m0 ? 0 : (m180 ? 2 : -1);
+                } else {
+                    int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+                    for (int j = 0; j < U; j++) {
+                        uint8_t v = d[i + j];
+                        if (v == uwc[0][j]) cnt0++;
+                        else if (v == uwc[1][j]) cnt1++;
+                        else if (v == uwc[2][j]) cnt2++;
+                        else if (v == uwc[3][j]) cnt3++;
+                    }
+                    code = cnt0 == U ? 0 : (cnt1 == U ? 1 : (cnt2 == U ? 2 : (cnt3 == U ? 3 : -1)));
+                }
+            }
+            ev[tid] = (signed char)code;
+            const int any = __syncthreads_or(code >= 0);
+            if (any && tid == 0) {
+                for (int t = 0; t < 256; t++) {
+                    const int cd = ev[t];
+                    if (cd < 0) continue;
+                    if (kind == SDRX_BPSK) {
+                        if (cd == 0) { if (--s_cc[0] <= 0) s_cc[0] = 0; }   // --cc: BPSK.cpp:468
+                        else { if (++s_cc[0] >= 10) s_cc[0] = 10; }          // ++cc: BPSK.cpp:473
+                    } else {
+                        for (int k = 0; k < 4; k++) {                         // QPSK.cpp:446-477
+                            if (k == cd) { if (++s_cc[k] >= 10) s_cc[k] = 10; }
+                            else { if (--s_cc[k] <= 0) s_cc[k] = 0; }
+                        }
+                    }
+                    if (hits && (size_t)s_nh < max_hits)
+                        hits[c * max_hits + s_nh] = ((unsigned long long)(base + t) << 3) | (unsigned long long)cd;
+                    s_nh++;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        int lut = -1;
+        if (kind == SDRX_BPSK) {
+            if (s_cc[0] >= 5) lut = 2; // BPSK.cpp:478 high_confidence() -> LUT_180
+        } else {                       // QPSK.cpp:481-507
+            if (s_cc[1] >= 5) lut = 1;
+            else if (s_cc[2] >= 5) lut = 2;
+            else if (s_cc[3] >= 5) lut = 3;
+        }
+        s_lut = lut;
+        for (int k = 0; k < 4; k++) st->cc[k] = s_cc[k];
+        st->n_hits = s_nh;
+    }
+    __syncthreads();
+    const int lut = s_lut;
+    if (lut < 0) return;
+    for (size_t i = tid; i < m; i += 256) {
+        const unsigned v = d[i];
+        unsigned o;
+        if (kind == SDRX_BPSK) o = v ^ 1u;                       // LUT_180 = {1,0}, BPSK.cpp:15
+        else if (lut == 1) o = (0x1302u >> (4 * (v & 3))) & 0xf; // LUT_REAL__90 = {2,0,3,1}, QPSK.cpp:17
+        else if (lut == 2) o = 3u - (v & 3);                     // LUT_REAL_180 = {3,2,1,0}, QPSK.cpp:18
+        else o = (0x2031u >> (4 * (v & 3))) & 0xf;               // LUT_REAL_270 = {1,3,0,2}, QPSK.cpp:19
+        d[i] = (uint8_t)o;
+    }
+}
+
+int launch_psk_ambiguity(int kind, uint8_t *decisions, size_t m, size_t nchan, size_t out_pitch,
+                         sdrx_psk_state *states, hipStream_t s)
+{
+    if (!decisions || !states || (kind != SDRX_BPSK && kind != SDRX_QPSK)) {
+        set_error("psk_ambiguity: bad argument");
+        return SDRX_EINVAL;
+    }
+    if (nchan == 0) return SDRX_OK;
+    if (nchan > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
+    hipLaunchKernelGGL(psk_ambiguity_kernel, dim3((unsigned)nchan), dim3(256), 0, s, kind, decisions, m, out_pitch,
+                       states, (unsigned long long *)nullptr, (size_t)0);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+int launch_psk_ambiguity_hits(int kind, uint8_t *decisions, size_t m, size_t nchan, size_t out_pitch,
+                              sdrx_psk_state *states, unsigned long long *hits, size_t max_hits, hipStream_t s)
+{
+    if (!decisions || !states) return SDRX_EINVAL;
+    if (nchan == 0) return SDRX_OK;
+    hipLaunchKernelGGL(psk_ambiguity_kernel, dim3((unsigned)nchan), dim3(256), 0, s, kind, decisions, m, out_pitch,
+                       states, hits, max_hits);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+// --------------------------------------------------------------------------------- modulator
+//
+// out[i] (+)= sum_j up[i-j] * RRC[128-j], j ascending, up = symbols zero-stuffed by 8: only
+// j == i (mod 8) meets a symbol, every other product is an exact zero and is skipped.
+__device__ const double d_rrc[129] = {
+    -0.000882663055055987, -0.000746201590523265, -0.000336789968798916, 0.000225038893553655,
+    0.000757880681389978,  0.001077943504359050,  0.001062303725777150,  0.000695521249813576,
+    8.24465490986367e-05,  -0.000579554041955506, -0.001062303725777150, -0.001183702054816000,
+    -0.000874477709296126, -0.000211083163638599, 0.000599193283619645,  0.001279536876191750,
+    0.001573979573701230,  0.001338143762729140,  0.000599193283619642,  -0.000438236415412023,
+    -0.001446863119017230, -0.002078893324143190, -0.002084671221261930, -0.001408617284422990,
+    -0.000227352605090172, 0.001088699270085450,  0.002084671221261940,  0.002371289907799650,
+    0.001768388256576610,  0.000391988582678128,  -0.001351122110122730, -0.002869993360503870,
+    -0.003572683794274230, -0.003072685906611650, -0.001351122110122720, 0.001186107048403510,
+    0.003789403406949890,  0.005575980755162950,  0.005816670050933640,  0.004213278581633850,
+    0.001071805138282270,  -0.002702696087965530, -0.005816670050933650, -0.006968745846090550,
+    -0.005305164769729840, -0.000815536975401244, 0.005468827588591990,  0.011573823048484000,
+    0.015005271935951800,  0.013430574641186900,  0.005468827588591980,  -0.008615615450369140,
+    -0.026525823848649200, -0.044008760276746200, -0.055452254485567400, -0.054931750238658300,
+    -0.037513179839879400, -0.000532386899804849, 0.055452254485567400,  0.126288206185736000,
+    0.204577471545948000,  0.280728910881642000,  0.344536138081295000,  0.386975375596443000,
+    0.401855774335913000,  0.386975375596443000,  0.344536138081295000,  0.280728910881642000,
+    0.204577471545948000,  0.126288206185736000,  0.055452254485567400,  -0.000532386899804849,
+    -0.037513179839879400, -0.054931750238658300, -0.055452254485567400, -0.044008760276746200,
+    -0.026525823848649200, -0.008615615450369140, 0.005468827588591980,  0.013430574641186900,
+    0.015005271935951800,  0.011573823048484000,  0.005468827588591990,  -0.000815536975401244,
+    -0.005305164769729840, -0.006968745846090550, -0.005816670050933650, -0.002702696087965530,
+    0.001071805138282270,  0.004213278581633850,  0.005816670050933640,  0.005575980755162950,
+    0.003789403406949890,  0.001186107048403510,  -0.001351122110122720, -0.003072685906611650,
+    -0.003572683794274230, -0.002869993360503870, -0.001351122110122730, 0.000391988582678128,
+    0.001768388256576610,  0.002371289907799650,  0.002084671221261940,  0.001088699270085450,
+    -0.000227352605090172, -0.001408617284422990, -0.002084671221261930, -0.002078893324143190,
+    -0.001446863119017230, -0.000438236415412023, 0.000599193283619642,  0.001338143762729140,
+    0.001573979573701230,  0.001279536876191750,  0.000599193283619645,  -0.000211083163638599,
+    -0.000874477709296126, -0.001183702054816000, -0.001062303725777150, -0.000579554041955506,
+    8.24465490986367e-05,  0.000695521249813576,  0.001062303725777150,  0.001077943504359050,
+    0.000757880681389978,  0.000225038893553655,  -0.000336789968798916, -0.000746201590523265,
+    -0.000882663055055987};
+
+__global__ void __launch_bounds__(256) psk_modulate_kernel(int kind, const uint8_t *__restrict__ sym, size_t len,
+                                                           double *__restrict__ out_re,
+                                                           double *__restrict__ out_im, size_t zero_prefix)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len * 8) return;
+    double ar = (i < zero_prefix) ? 0.0 : out_re[i]; // memset(out, 0, output_length) clears BYTES: BPSK.cpp:131
+    double ai = 0.0;
+    if (kind == SDRX_QPSK) ai = (i < zero_prefix) ? 0.0 : out_im[i];
+    for (size_t j = i & 7; j <= 128 && j <= i; j += 8) { // BPSK.cpp:137-143
+        const size_t s = (i - j) >> 3;
+        if (s >= len) continue;
+        const unsigned v = sym[s];
+        const double h = d_rrc[128 - j];
+        if (kind == SDRX_BPSK) {
+            ar += ((v & 1) ? -1.0 : 1.0) * h; // LUT_REAL = {1,-1}, BPSK.cpp:14
+        } else {
+            ar += ((v & 1) ? -1.0 : 1.0) * h; // LUT_REAL = {1,-1,1,-1}, QPSK.cpp:14
+            ai += ((v & 2) ? -1.0 : 1.0) * h; // LUT_IMAG = {1,1,-1,-1}, QPSK.cpp:15
+        }
+    }
+    out_re[i] = ar;
+    if (kind == SDRX_QPSK) out_im[i] = ai;
+}
+
+int launch_psk_modulate(int kind, const uint8_t *sym, size_t len, double *out_re, double *out_im, size_t zero_prefix,
+                        hipStream_t s)
+{
+    if (!sym || !out_re || (kind == SDRX_QPSK && !out_im) || (kind != SDRX_BPSK && kind != SDRX_QPSK)) {
+        set_error("psk_modulate: bad argument");
+        return SDRX_EINVAL;
+    }
+    if (len == 0) return SDRX_OK;
+    size_t blocks = (len * 8 + 255) / 256;
+    if (blocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
+    hipLaunchKernelGGL(psk_modulate_kernel, dim3((unsigned)blocks), dim3(256), 0, s, kind, sym, len, out_re, out_im,
+                       zero_prefix);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+} // namespace sdrx

@@ -1,0 +1,56 @@
+// sdrx_internal.h -- shared between the translation units of libsdrx.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/sdrx.h"
+
+namespace sdrx {
+
+void set_error(const char *fmt, ...);
+
+#define SDRX_HIP(call)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            sdrx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SDRX_EHIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+// Smallest double s with sqrt_rn(s) >= 80 (AM<T>::THRESHOLD, AM.h:23).  The kernels compare the
+// squared magnitude against it, which equals `sqrt(re*re+im*im) >= 80` of AM.h:73 for every input
+// because IEEE sqrt is monotone; found on the host by stepping down from 6400 with nextafter.
+double am_threshold_sq();
+
+// 32-bit magic for q = u / d, exact for u < 2^20, 1 <= d < 2^11  (q = (u * magic) >> 32)
+inline unsigned magic_u32(unsigned d) { return (unsigned)((0x100000000ULL + d - 1) / d); }
+
+// launchers implemented in fir_kernels.hip
+enum FirEpilogue { EPI_STORE = 0, EPI_AM = 1, EPI_DISC = 2 };
+int launch_fir(const sdrx_fir_job *job, FirEpilogue epi);
+
+// demod_kernels.hip
+int launch_am_demod(const double *re, const double *im, uint8_t *out, size_t n, size_t ds, hipStream_t s);
+int launch_ones_zeros(const double *re, const double *im, size_t n, int32_t *count, hipStream_t s);
+int launch_fm_demod(const double *re, const double *w1, const double *w2, uint8_t *out, size_t n, size_t ds,
+                    hipStream_t s);
+
+// psk_kernels.hip
+int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch, sdrx_psk_state *states,
+                     uint8_t *decisions, size_t out_pitch, int run_timing, int run_phase, hipStream_t s);
+int launch_psk_ambiguity(int kind, uint8_t *decisions, size_t m, size_t nchan, size_t out_pitch,
+                         sdrx_psk_state *states, hipStream_t s);
+int launch_psk_ambiguity_hits(int kind, uint8_t *decisions, size_t m, size_t nchan, size_t out_pitch,
+                              sdrx_psk_state *states, unsigned long long *hits, size_t max_hits, hipStream_t s);
+int launch_psk_modulate(int kind, const uint8_t *sym, size_t len, double *out_re, double *out_im, size_t zero_prefix,
+                        hipStream_t s);
+const double *psk_mf_taps_dev(); // RRC reversed (h[k] = RRC[128-k]), device resident, created on first use
+const double *zero_state_dev(size_t doubles); // device buffer of >= `doubles` zeros (grown on demand, never written)
+extern const double RRC_COEFF[129];
+
+} // namespace sdrx

@@ -1,0 +1,147 @@
+"""Device-resident entry points of libsdrx (include/sdrx.h, layer 1) driven from torch tensors.
+
+torch is plumbing only: device memory, streams, torch.distributed.  Every compute call goes to
+the hand-written HIP kernels through the C ABI with raw device pointers.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def init(device_index=0):
+    _lib.check(_lib.lib().sdrx_init(int(device_index)), "sdrx_init")
+
+
+class FirChain:
+    """FIR (+ fused demod) over `nchan` independent channels with carried state.
+
+    Mirrors Filter objects on I and Q (filt.cpp:236-273) per channel: hist = the shift register,
+    pre = the discriminator's previous sample (rtl_fm.c:523,543-544)."""
+
+    def __init__(self, taps, nchan=1, decim=1, device="cuda"):
+        self.L = _lib.lib()
+        taps = np.ascontiguousarray(taps, dtype=np.float64)
+        self.T = int(taps.size)
+        self.decim = int(decim)
+        self.nchan = int(nchan)
+        self.device = torch.device(device)
+        self.taps = torch.from_numpy(taps).to(self.device)
+        self.pitch = int(self.L.sdrx_fir_state_doubles(self.T))
+        self.state = [torch.zeros(self.nchan, self.pitch, dtype=torch.float64, device=self.device) for _ in range(2)]
+        self.cur = 0
+
+    def reset(self):
+        for s in self.state:
+            s.zero_()
+        self.cur = 0
+
+    def n_out(self, n):
+        return (n + self.decim - 1) // self.decim
+
+    def _job(self, layout, in0, in1, n, in_pitch, out0, out1, out_pitch, fast_fma, n_out):
+        j = _lib.FirJob()
+        j.layout = layout
+        j.fast_fma = 1 if fast_fma else 0
+        j.in0, j.in1 = _ptr(in0), _ptr(in1)
+        j.n, j.nchan, j.in_pitch = n, self.nchan, in_pitch
+        j.taps, j.num_taps, j.decim = _ptr(self.taps), self.T, self.decim
+        j.state_in, j.state_out = _ptr(self.state[self.cur]), _ptr(self.state[self.cur ^ 1])
+        j.state_pitch = self.pitch
+        j.out0, j.out1, j.out_pitch, j.n_out = _ptr(out0), _ptr(out1), out_pitch, n_out
+        j.stream = _stream()
+        return j
+
+    def _run(self, fn, name, layout, in0, in1, n, in_pitch, out0, out1, out_pitch, fast_fma=False, n_out=0):
+        j = self._job(layout, in0, in1, n, in_pitch, out0, out1, out_pitch, fast_fma, n_out)
+        _lib.check(fn(C.byref(j)), name)
+        self.cur ^= 1
+
+    # x: (nchan, n, 2) interleaved complex f64, or (re, im) tuple of (nchan, n), or a single real (nchan, n)
+    @staticmethod
+    def _inputs(x):
+        if isinstance(x, (tuple, list)):
+            re, im = x
+            assert re.dtype == torch.float64 and re.is_contiguous() and im.is_contiguous()
+            return _lib.IQ_SPLIT, re, im, re.shape[-1], re.shape[-1]
+        assert x.dtype == torch.float64 and x.is_contiguous()
+        if x.dim() == 3 and x.shape[-1] == 2:
+            return _lib.IQ_INTERLEAVED, x, None, x.shape[1], x.shape[1]
+        return _lib.REAL, x, None, x.shape[-1], x.shape[-1]
+
+    def fir(self, x, out0, out1=None, fast_fma=False, n_out=0):
+        layout, in0, in1, n, pitch = self._inputs(x)
+        op = out0.shape[1]
+        self._run(self.L.sdrx_fir_dev, "sdrx_fir_dev", layout, in0, in1, n, pitch, out0, out1, op, fast_fma, n_out)
+
+    def fir_am(self, x, bits, fast_fma=False):
+        layout, in0, in1, n, pitch = self._inputs(x)
+        self._run(self.L.sdrx_fir_am_dev, "sdrx_fir_am_dev", layout, in0, in1, n, pitch, bits, None, bits.shape[1],
+                  fast_fma)
+
+    def fir_fmdisc(self, x, angle, fast_fma=False):
+        layout, in0, in1, n, pitch = self._inputs(x)
+        self._run(self.L.sdrx_fir_fmdisc_dev, "sdrx_fir_fmdisc_dev", layout, in0, in1, n, pitch, angle, None,
+                  angle.shape[1], fast_fma)
+
+
+def am_demod(re, im, out, ds):
+    _lib.check(_lib.lib().sdrx_am_demod_dev(_ptr(re), _ptr(im), _ptr(out), re.numel(), int(ds), _stream()),
+               "sdrx_am_demod_dev")
+
+
+def ones_zeros(re, im, count):
+    _lib.check(_lib.lib().sdrx_ones_zeros_dev(_ptr(re), _ptr(im), re.numel(), _ptr(count), _stream()),
+               "sdrx_ones_zeros_dev")
+
+
+def fm_demod(re, w1, w2, out, ds):
+    _lib.check(_lib.lib().sdrx_fm_demod_dev(_ptr(re), _ptr(w1), _ptr(w2), _ptr(out), re.numel(), int(ds), _stream()),
+               "sdrx_fm_demod_dev")
+
+
+class PskBank:
+    """nchan independent BPSK or QPSK demodulators (BPSK.cpp:148-176 / QPSK.cpp:190-219), device resident."""
+
+    def __init__(self, kind, nchan, n, unique_word=None, uw_len=None, device="cuda"):
+        self.L = _lib.lib()
+        self.kind, self.nchan, self.n = int(kind), int(nchan), int(n)
+        self.device = torch.device(device)
+        st = _lib.PskState()
+        if kind == _lib.BPSK:
+            self.L.sdrx_psk_state_init_bpsk(C.byref(st), 0x4E if unique_word is None else int(unique_word),
+                                            8 if uw_len is None else int(uw_len))
+        else:
+            uw = None
+            if unique_word is not None:
+                self._uw = np.ascontiguousarray(unique_word, dtype=np.float64)
+                uw = self._uw.ctypes.data_as(C.c_void_p)
+            self.L.sdrx_psk_state_init_qpsk(C.byref(st), uw, 16 if uw_len is None else int(uw_len))
+        self.state_bytes = C.sizeof(_lib.PskState)
+        one = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8)
+        self.states = one.repeat(self.nchan, 1).contiguous().to(self.device)
+        self.work = torch.empty(int(self.L.sdrx_psk_work_bytes(self.n, self.nchan)), dtype=torch.uint8,
+                                device=self.device)
+        self.n_dec = (self.n // 4 + 1) // 2
+
+    def demod(self, iq, out):
+        """iq: (nchan, n, 2) f64; out: (nchan, >= n/8) uint8."""
+        assert iq.dtype == torch.float64 and iq.is_contiguous() and iq.shape[1] == self.n
+        _lib.check(self.L.sdrx_psk_demod_dev(self.kind, _ptr(iq), self.n, self.nchan, self.n, _ptr(self.states),
+                                             _ptr(out), out.shape[1], _ptr(self.work), _stream()),
+                   "sdrx_psk_demod_dev")
+
+    def host_states(self):
+        raw = self.states.cpu().numpy().tobytes()
+        return [_lib.PskState.from_buffer_copy(raw[i * self.state_bytes:(i + 1) * self.state_bytes])
+                for i in range(self.nchan)]

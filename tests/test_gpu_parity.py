@@ -1,0 +1,465 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's
+golden vectors.  Bar: bit-exact for bits / symbol decisions AND for filtered samples, loop state
+and discriminator output (the kernels keep the reference's operation order without FMA
+contraction; oracle in ORC_MATH_SHARED mode for the two transcendental calls).  Only the
+`fast_fma` variant is compared with a tolerance (1e-12 relative to sum|h||x|, stated in its test).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from signals import fm_iq, ook_iq, psk_symbols, psk_test_signal, radio_iq
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from sdr_amd import _lib, device, host  # noqa: E402
+
+L = O.lib()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    device.init(0)
+    yield
+    torch.cuda.synchronize()
+
+
+def G(golden, key):
+    return np.array(golden[key])
+
+
+# =============================================================================== Filter
+
+@pytest.mark.parametrize("ftype,Fx,Fu", [(O.LPF, 1.0e5, None), (O.HPF, 3.0e5, None), (O.BPF, 1.0e5, 4.0e5)])
+@pytest.mark.parametrize("T", [1, 2, 51, 64, 129, 1000])
+def test_filter_execute_streaming(ftype, Fx, Fu, T):
+    """Filter::execute (filt.cpp:267-273): taps and outputs bit-identical over ragged chunks."""
+    f = host.Filter(ftype, T, 2.0e6, Fx, Fu)
+    o = O.Fir(ftype, T, 2.0e6, Fx, Fu)
+    assert f.get_error_flag() == 0 == o.err
+    assert np.array_equal(f.get_taps(), o.taps)
+    rng = np.random.default_rng(T * 7 + ftype)
+    x = rng.integers(-127, 128, 20000).astype(np.float64) + rng.uniform(-0.5, 0.5, 20000)
+    for lo, hi in ((0, 1), (1, 2), (2, 1300), (1300, 1301 + T), (1301 + T, 20000)):
+        a = x[lo:hi].copy()
+        f.execute(a)
+        b = o.execute(x[lo:hi], fast=True)
+        assert np.array_equal(a, b), (lo, hi)
+    f.init()  # Filter::init clears the shift register
+    o2 = O.Fir(ftype, T, 2.0e6, Fx, Fu)
+    a = x[:500].copy()
+    f.execute(a)
+    assert np.array_equal(a, o2.execute(x[:500], fast=True))
+
+
+def test_filter_do_sample_and_errors():
+    """do_sample (filt.cpp:248-265) and the constructor's error codes (filt.cpp:54-67,85-99)."""
+    f = host.Filter(O.LPF, 51, 44.1, 4.0)
+    o = O.Fir(O.LPF, 51, 44.1, 4.0)
+    xs = np.linspace(-3, 5, 40)
+    got = np.array([f.do_sample(v) for v in xs])
+    assert np.array_equal(got, o.execute(xs))
+    cases = [((O.LPF, 64, 0.0, 1.0, None), -1), ((O.LPF, 64, 2e6, 0.0, None), -2), ((O.LPF, 64, 2e6, 1e6, None), -2),
+             ((O.LPF, 0, 2e6, 1e5, None), -3), ((O.LPF, 1001, 2e6, 1e5, None), -3), ((O.BPF, 64, 2e6, 1e5, None), -5),
+             ((O.BPF, 64, 0.0, 1.0, 2.0), -10), ((O.BPF, 64, 2e6, 2e5, 1e5), -11), ((O.BPF, 64, 2e6, 0.0, 1e5), -12),
+             ((O.BPF, 64, 2e6, 1e5, 1e6), -13), ((O.BPF, 1024, 2e6, 1e5, 2e5), -14), ((O.LPF, 64, 2e6, 1e5, 2e5), -16)]
+    for (ft, T, Fs, Fx, Fu), code in cases:
+        g = host.Filter(ft, T, Fs, Fx, Fu)
+        assert g.get_error_flag() == code
+        buf = np.ones(16)
+        g.execute(buf)  # do_sample returns 0 once the flag is set (filt.cpp:254)
+        assert np.all(buf == 0)
+        assert g.do_sample(1.0) == 0.0
+
+
+def test_filter_1024_taps_cap_lifted():
+    """BASELINE config 5 needs T = 1024; the reference rejects it (-3).  With the cap lifted the
+    restatement of filt.cpp:116-121,248-265 is the checker."""
+    assert host.Filter(O.LPF, 1024, 2.0e6, 1.0e5).get_error_flag() == -3
+    f = host.Filter(O.LPF, 1024, 2.0e6, 1.0e5, max_taps=4096)
+    o = O.Fir(O.LPF, 1024, 2.0e6, 1.0e5, max_taps=4096)
+    assert f.get_error_flag() == 0 == o.err
+    rng = np.random.default_rng(5)
+    x = rng.integers(-127, 128, 50000).astype(np.float64)
+    a = x.copy()
+    f.execute(a)
+    assert np.array_equal(a, o.execute(x, fast=True))
+
+
+# =============================================================================== AM
+
+def test_am_golden(golden):
+    """TEST(AM, modulate / demodulate / ModDemod): TEST_AM.cpp:14-58, TEST_Modulator_Demodulator.cpp:123-162."""
+    bits = G(golden, "TEST_AM__AM__modulate__inputStream")
+    am = host.AM()
+    mod = np.zeros(8000)
+    am.modulate(bits, 1000, mod, None, 8000)
+    assert np.array_equal(mod, G(golden, "TEST_AM__AM__modulate__modulatedStream"))
+    x = G(golden, "TEST_AM__AM__demodulate__modulatedStream") * 127.0
+    out = np.zeros(1000, dtype=np.uint8)
+    assert am.demodulate(x, x, out, 8000, 8) == 1000
+    assert np.array_equal(out, G(golden, "TEST_AM__AM__demodulate__ouputStream"))
+
+
+@pytest.mark.parametrize("ds", [1, 8, 7, 100])
+def test_am_demod_vs_oracle(ds):
+    n = 100003
+    re, im = radio_iq(n, 11)
+    # values on and around the decision boundary sqrt(re^2+im^2) == 80 (AM.h:73)
+    re[:6] = [80.0, 48.0, np.nextafter(80.0, 0), 0.0, 79.99999999999997, 56.568542494923804]
+    im[:6] = [0.0, 64.0, 0.0, np.nextafter(80.0, 100), 0.0, 56.568542494923804]
+    out = np.zeros(n, dtype=np.uint8)
+    m = host.AM().demodulate(re, im, out, n, ds)
+    want = O.am_demodulate(re, im, ds)
+    assert m == want.size
+    assert np.array_equal(out[:m], want)
+
+
+def test_am_threshold_boundary_exhaustive():
+    """The kernels compare re^2+im^2 with the smallest double whose rounded sqrt is >= 80; sweep the
+    500 doubles either side of 6400 to show this equals sqrt(...) >= 80 bit for bit."""
+    s = 6400.0
+    vals = [s]
+    lo = hi = s
+    for _ in range(500):
+        lo = np.nextafter(lo, 0)
+        hi = np.nextafter(hi, 1e9)
+        vals += [lo, hi]
+    v = np.array(vals)
+    re = np.sqrt(v)  # re^2 lands near 6400 in many different roundings
+    im = np.zeros_like(re)
+    out = np.zeros(v.size, dtype=np.uint8)
+    host.AM().demodulate(re, im, out, v.size, 1)
+    assert np.array_equal(out, O.am_demodulate(re, im, 1))
+
+
+def test_ones_zeros_and_legacy_am():
+    """ones_zeros_demodulation (ones_zeros.cu:28-52 / rtlsdr_receiver.cpp:2063-2086) and the
+    am_gpu_* legacy symbols (am.cu:94-152) incl. ProfileTest's ramp input (ProfileTest/main.cpp:124-135)."""
+    Lx = _lib.lib()
+    n = 512000
+    buf = (np.arange(n) % 255).astype(np.float64)
+    Lx.am_gpu_initialize(n, 2)
+    out = np.zeros(n, dtype=np.uint8)
+    for radio in (0, 1):
+        t = Lx.am_gpu_demodulation(radio, buf.ctypes.data, buf.ctypes.data, out.ctypes.data, n, 1)
+        assert t > 0
+        assert np.array_equal(out, O.am_demodulate(buf, buf, 1))
+    Lx.am_gpu_free()
+    re, im = radio_iq(300001, 3)
+    assert Lx.ones_zeros_demodulation(re.ctypes.data, im.ctypes.data, re.size) == L.orc_ones_zeros(re, im, re.size)
+
+
+# =============================================================================== FM (FSK)
+
+def test_fm_golden(golden):
+    """TEST(FM, modulate / demodulate / ModDemodResampled): TEST_FM.cpp:14-99."""
+    bits = G(golden, "TEST_FM__FM__modulate__inputStream")
+    fm = host.FM(100, 10, 20, 10)
+    mod = np.zeros(1000)
+    fm.modulate(bits, 10, mod, None, 1000, 100)
+    assert np.allclose(mod, G(golden, "TEST_FM__FM__modulate__modulatedStream"), rtol=0, atol=1e-9)
+    x = G(golden, "TEST_FM__FM__demodulate__modulatedRealStream")
+    out = np.zeros(10, dtype=np.uint8)
+    assert host.FM(100, 100, 20, 10).demodulate(x, np.zeros(1000), out, 1000, 100) == 10
+    assert np.array_equal(out, G(golden, "TEST_FM__FM__demodulate__outputStream"))
+    stream = G(golden, "TEST_FM__FM__ModDemodResampled__modulatedStream").copy()
+    L.orc_decimate(stream, 1000, 2)
+    half = stream[:500].copy()
+    out2 = np.zeros(10, dtype=np.uint8)
+    assert host.FM(100, 50, 20, 10).demodulate(half, half, out2, 500, 50) == 10
+    assert np.array_equal(out2, G(golden, "TEST_FM__FM__ModDemodResampled__outputStream"))
+
+
+@pytest.mark.parametrize("ds", [1, 2, 31, 32, 33, 100, 333, 2000])
+def test_fm_demod_vs_oracle(ds):
+    """FM<T>::demodulate (FM.h:83-148): bits identical on noisy FSK and on pure noise (ties matter)."""
+    rng = np.random.default_rng(ds)
+    nbits = 700
+    bits = rng.integers(0, 2, nbits).astype(np.uint8)
+    x = O.fm_modulate(2.0e6, 19000.0, 20000.0, bits, ds) * 40 + rng.normal(0, 1.0, nbits * ds)
+    x = np.concatenate([x, rng.normal(0, 1, ds // 2)])  # ragged tail: n not a multiple of ds
+    out = np.zeros(nbits + 4, dtype=np.uint8)
+    m = host.FM(10e6, 2.0e6).demodulate(x, x, out, x.size, ds)
+    want = O.fm_demodulate(2.0e6, 19000.0, 20000.0, x, ds)
+    assert m == want.size == nbits
+    assert np.array_equal(out[:m], want)
+
+
+def test_legacy_fm_symbols():
+    """fm_gpu_* (fm.cu:48-167) with ProfileTest's arguments (ProfileTest/main.cpp:160,184)."""
+    Lx = _lib.lib()
+    n = 512000
+    buf = (np.arange(n) % 255).astype(np.float64)
+    Lx.fm_gpu_initialize(1, n, 2000000, 100, 10.0, 20.0)
+    out = np.zeros(n // 100, dtype=np.uint8)
+    Lx.fm_gpu_demodulation(0, buf.ctypes.data, buf.ctypes.data, out.ctypes.data, n, 100)
+    assert np.array_equal(out, O.fm_demodulate(2000000.0, 10.0, 20.0, buf, 100))
+    Lx.fm_gpu_set_samples_per_bit(50, 0)  # the receiver's one-argument call: rate falls back to init
+    out2 = np.zeros(n // 50, dtype=np.uint8)
+    Lx.fm_gpu_demodulation(0, buf.ctypes.data, buf.ctypes.data, out2.ctypes.data, n, 50)
+    assert np.array_equal(out2, O.fm_demodulate(2000000.0, 10.0, 20.0, buf, 50))
+    Lx.fm_gpu_free()
+
+
+# =============================================================================== chains
+
+def _oracle_chain_am(taps, re, im, ds, hI, hQ):
+    bits = np.zeros((re.size + ds - 1) // ds + 1, dtype=np.uint8)
+    m = L.orc_chain_fir_am(taps, taps.size, hI, hQ, re, im, re.size, ds, bits)
+    return bits[:m]
+
+
+def _oracle_chain_disc(taps, re, im, D, hI, hQ, pre):
+    out = np.zeros((re.size + D - 1) // D + 1)
+    m = L.orc_chain_fir_decim_disc(taps, taps.size, hI, hQ, pre, re, im, re.size, D, out, O.MATH_SHARED)
+    return out[:m]
+
+
+@pytest.mark.parametrize("ds", [1, 8, 100])
+def test_chain_fir_am_host(ds):
+    """BASELINE config 1: Filter(LPF,64,2e6,1e5) on I and Q, AM::demodulate(ds); streamed in chunks."""
+    err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
+    n = 1 << 17
+    re, im, _ = ook_iq(n, 1, ds=8)
+    ch = host.Chain(taps, ds)
+    hI, hQ = np.zeros(63), np.zeros(63)
+    step = 40000  # multiple of ds for every ds tested
+    for k in range(0, n, step):
+        r, i = re[k:k + step].copy(), im[k:k + step].copy()
+        got = ch.fir_am(r, i)
+        want = _oracle_chain_am(taps, r, i, ds, hI, hQ)
+        assert np.array_equal(got, want), k
+
+
+@pytest.mark.parametrize("D,T", [(10, 64), (1, 64), (2, 33), (3, 64), (4, 129), (7, 20), (16, 64), (64, 64), (100, 64), (10, 1), (10, 2)])
+def test_chain_fir_fmdisc_host(D, T):
+    """BASELINE config 2: LPF -> decimate by D -> phase-difference discriminator; every FIR register
+    blocking (R = 8, 4, 2, 1), gather tiles (D >= T) and the state carry across ragged chunks."""
+    err, taps = O.fir_design(O.LPF, T, 2.4e6, 1.0e5)
+    assert err == 0
+    n = 200000
+    re, im = fm_iq(n, seed=2)
+    ch = host.Chain(taps, D)
+    hI, hQ, pre = np.zeros(max(T - 1, 1)), np.zeros(max(T - 1, 1)), np.zeros(2)
+    cuts = [0, D * 3, D * 3 + D * 1000, D * 3 + D * 1000 + D * 7919, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        r, i = re[lo:hi].copy(), im[lo:hi].copy()
+        got = ch.fir_fmdisc(r, i)
+        want = _oracle_chain_disc(taps, r, i, D, hI, hQ, pre)
+        assert got.size == want.size
+        assert np.array_equal(got, want), (lo, hi, np.flatnonzero(got != want)[:5])
+
+
+def test_chain_device_layouts_multichannel():
+    """Device layer: 5 channels, split and interleaved layouts give the same bits/angles as the oracle."""
+    err, taps = O.fir_design(O.LPF, 64, 2.4e6, 1.0e5)
+    C_, n, D = 5, 70001, 10
+    res, ims = zip(*[fm_iq(n, seed=40 + c) for c in range(C_)])
+    re = torch.tensor(np.stack(res), device="cuda")
+    im = torch.tensor(np.stack(ims), device="cuda")
+    iq = torch.stack([re, im], dim=-1).contiguous()
+    n_out = (n + D - 1) // D
+    for x in ((re, im), iq):
+        ch = device.FirChain(taps, nchan=C_, decim=D)
+        ang = torch.zeros(C_, n_out, dtype=torch.float64, device="cuda")
+        ch.fir_fmdisc(x, ang)
+        # second call continues the streams
+        ang2 = torch.zeros(C_, n_out, dtype=torch.float64, device="cuda")
+        ch.fir_fmdisc(x, ang2)
+        torch.cuda.synchronize()
+        for c in range(C_):
+            hI, hQ, pre = np.zeros(63), np.zeros(63), np.zeros(2)
+            w1 = _oracle_chain_disc(taps, res[c], ims[c], D, hI, hQ, pre)
+            w2 = _oracle_chain_disc(taps, res[c], ims[c], D, hI, hQ, pre)
+            assert np.array_equal(ang[c].cpu().numpy(), w1)
+            assert np.array_equal(ang2[c].cpu().numpy(), w2)
+    ch = device.FirChain(taps, nchan=C_, decim=1)
+    bits = torch.zeros(C_, n, dtype=torch.uint8, device="cuda")
+    ch.fir_am(iq * 1.0, bits)
+    torch.cuda.synchronize()
+    for c in range(C_):
+        assert np.array_equal(bits[c].cpu().numpy(), _oracle_chain_am(taps, res[c], ims[c], 1, np.zeros(63), np.zeros(63)))
+
+
+def test_fast_fma_within_tolerance():
+    """fast_fma = 1 fuses multiply-add: not bit-exact; bound |err| <= 1e-12 * sum|h||x| (north_star's fp64 tolerance)."""
+    err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
+    n = 100000
+    re, im = radio_iq(n, 9)
+    x = torch.tensor(np.stack([re, im], axis=-1)[None], device="cuda")
+    ch = device.FirChain(taps, nchan=1, decim=1)
+    o0 = torch.zeros(1, n, dtype=torch.float64, device="cuda")
+    o1 = torch.zeros(1, n, dtype=torch.float64, device="cuda")
+    ch.fir(x, o0, o1, fast_fma=True)
+    torch.cuda.synchronize()
+    want = O.Fir(O.LPF, 64, 2.0e6, 1.0e5).execute(re, fast=True)
+    scale = np.convolve(np.abs(re), np.abs(taps))[:n] + 1e-300
+    assert np.max(np.abs(o0[0].cpu().numpy() - want) / scale) <= 1e-12
+
+
+def test_full_size_streaming_property_and_spot_checks():
+    """BASELINE config 2 at full size (2^24 samples): (i) one launch == the same stream in 2^18-sample
+    chunks with state carried, bit for bit; (ii) 4000 outputs spot-checked against the oracle, which
+    recomputes each from its own 64-sample input window."""
+    err, taps = O.fir_design(O.LPF, 64, 2.4e6, 1.0e5)
+    n, D = 1 << 24, 10
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    iq = torch.randint(-127, 128, (1, n, 2), generator=g, device="cuda").to(torch.float64)
+    n_out = (n + D - 1) // D
+    one = torch.zeros(1, n_out, dtype=torch.float64, device="cuda")
+    device.FirChain(taps, 1, D).fir_fmdisc(iq, one)
+    ch = device.FirChain(taps, 1, D)
+    parts = []
+    chunk = 1 << 18  # not a multiple of 10: use a chunk that is
+    chunk = chunk - chunk % D
+    for k in range(0, n, chunk):
+        x = iq[:, k:k + chunk].contiguous()
+        o = torch.zeros(1, (x.shape[1] + D - 1) // D, dtype=torch.float64, device="cuda")
+        ch.fir_fmdisc(x, o)
+        parts.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts, dim=1), one)
+    rng = np.random.default_rng(0)
+    ms = np.unique(np.concatenate([[0, 1, 2, n_out - 1], rng.integers(7, n_out, 4000)]))
+    host_iq = iq[0].cpu().numpy()
+    got = one[0].cpu().numpy()
+    for m in ms:
+        lo = max(0, (m - 1) * D - 63)
+        seg = host_iq[lo:m * D + 1]
+        re, im = np.ascontiguousarray(seg[:, 0]), np.ascontiguousarray(seg[:, 1])
+        # filter the window from zero history; exact whenever the window covers all 64 taps or starts at 0
+        fi = O.Fir(O.LPF, 64, 2.4e6, 1.0e5).execute(re, fast=True)
+        fq = O.Fir(O.LPF, 64, 2.4e6, 1.0e5).execute(im, fast=True)
+        cur = (fi[-1], fq[-1])
+        prev = (fi[-1 - D], fq[-1 - D]) if m > 0 else (0.0, 0.0)
+        want = O.fm_discriminator(np.array([prev[0], cur[0]]), np.array([prev[1], cur[1]]), math_mode=O.MATH_SHARED)[1]
+        assert got[m] == want, m
+
+
+# =============================================================================== PSK
+
+def test_bpsk_golden_stages(golden):
+    """TEST(BPSK, ...) ladder of TEST_BPSK.cpp + Full_ModDemod, through the drop-in stage methods."""
+    b = host.BPSK()
+    ps = G(golden, "TEST_BPSK__BPSK__decode_pulseShape__pulseShaped")[:800]
+    iq = np.zeros(1600)
+    iq[0::2] = ps
+    re, im = np.zeros(200), np.zeros(200)
+    assert b.decode_pulseShape(iq, re, im) == 200
+    assert np.allclose(re[:198], G(golden, "TEST_BPSK__BPSK__decode_pulseShape__RxCorrelated")[:198], rtol=0, atol=1e-5)
+    re = G(golden, "TEST_BPSK__BPSK__symbol_timing_synchronization__RxCorrelated_real")[:1000].copy()
+    im = G(golden, "TEST_BPSK__BPSK__symbol_timing_synchronization__RxCorrelated_imag")[:1000].copy()
+    host.BPSK().symbol_timing_synchronization(re, im, 1000)
+    assert np.allclose(re, G(golden, "TEST_BPSK__BPSK__symbol_timing_synchronization__RxSymbolSynchronized_real")[:1000], rtol=0, atol=1e-8)
+    assert np.allclose(im, G(golden, "TEST_BPSK__BPSK__symbol_timing_synchronization__RxSymbolSynchronized_imag")[:1000], rtol=0, atol=1e-8)
+    re = G(golden, "TEST_BPSK__BPSK__rx_phase_correction__RxCorrelated_real")[:1000].copy()
+    im = G(golden, "TEST_BPSK__BPSK__rx_phase_correction__RxCorrelated_imag")[:1000].copy()
+    assert host.BPSK().phase_shift_correction(re, im, 1000) == 500
+    assert np.array_equal(re[1:500], G(golden, "TEST_BPSK__BPSK__rx_phase_correction__RxSymbolSynchronized_real")[1:500])
+    x = G(golden, "TEST_BPSK__BPSK__phase_ambiguity_correction__RX_PHASE_CORRECTED")[:1000].copy()
+    host.BPSK().phase_ambiguity_correction(x, None, 1000)
+    assert np.array_equal(x[537:737], G(golden, "TEST_BPSK__BPSK__phase_ambiguity_correction__RX_PHASE_AMBIGUITY_DETECTED")[:200])
+    # Full_ModDemod: TEST_Modulator_Demodulator.cpp:12-61
+    bits = G(golden, "TEST_Modulator_Demodulator__BPSK__Full_ModDemod__input_stream")
+    bp = host.BPSK(0x14EB, 16)
+    mod = np.zeros(8000)
+    bp.modulate(bits, 1000, mod, 8000)
+    assert np.allclose(mod[:800], G(golden, "TEST_Modulator_Demodulator__BPSK__Full_ModDemod__modulated_stream")[:800], rtol=0, atol=1e-6)
+    out = bp.demodulate(np.repeat(mod, 2))
+    assert out.size == 1000
+    assert np.array_equal(out[:990], G(golden, "TEST_Modulator_Demodulator__BPSK__Full_ModDemod__output_stream")[:990])
+
+
+def test_qpsk_golden_stages(golden):
+    """TEST(QPSK, Deconstructed_ModDemod) TEST_QPSK.cpp:409-507 and Full_ModDemod."""
+    src = "TEST_QPSK__QPSK__Deconstructed_ModDemod"
+    sym = G(golden, f"{src}__input_stream")
+    q = host.QPSK()
+    mr, mi = np.zeros(8000), np.zeros(8000)
+    q.modulate(sym, 1000, mr, mi, 8000)
+    assert np.allclose(mr, G(golden, f"{src}__real_modulated_stream"), rtol=0, atol=1e-8)
+    assert np.allclose(mi, G(golden, f"{src}__imag_modulated_stream"), rtol=0, atol=1e-8)
+    iq = np.empty(16000)
+    iq[0::2], iq[1::2] = mr, mi
+    re, im = np.zeros(2000), np.zeros(2000)
+    assert q.decode_pulseShape(iq, re, im) == 2000
+    assert np.allclose(re, G(golden, f"{src}__real_correlated"), rtol=0, atol=1e-7)
+    assert np.allclose(im, G(golden, f"{src}__imag_correlated"), rtol=0, atol=1e-7)
+    q.symbol_timing_synchronization(re, im, 2000)
+    assert np.allclose(re, G(golden, f"{src}__real_timesync"), rtol=0, atol=1e-7)
+    assert np.allclose(im, G(golden, f"{src}__imag_timesync"), rtol=0, atol=1e-7)
+    assert q.phase_shift_correction(re, im, 2000) == 1000
+    assert np.array_equal(re[:1000], G(golden, f"{src}__real_phasecorrect"))
+    q.phase_ambiguity_correction(re, im, 1000)
+    amb = G(golden, f"{src}__real_phaseambcorrect")
+    assert np.array_equal(re[81:1000], amb[:919])
+    out = host.QPSK().demodulate(iq)
+    assert out.size == 1000 and np.array_equal(out[81:], amb[:919])
+
+
+@pytest.mark.parametrize("kind", [O.BPSK, O.QPSK])
+@pytest.mark.parametrize("phase_deg", [0.0, 90.0, 180.0, 270.0, 33.0])
+def test_psk_blocks_vs_oracle(kind, phase_deg):
+    """Three consecutive noisy blocks: decisions, all 24 loop-state doubles, counters and UW hits are
+    IDENTICAL to the oracle (shared-math mode); the oracle's libm mode (== compiled reference,
+    tests/test_oracle_vs_ref.py) makes the same decisions."""
+    uw = 0xDEADBEEF600DF00D
+    if kind == O.BPSK:
+        obj, st, st_libm = host.BPSK(uw, 64), O.psk_new(O.BPSK, uw, 64, O.MATH_SHARED), O.psk_new(O.BPSK, uw, 64, O.MATH_LIBM)
+    else:
+        obj, st, st_libm = host.QPSK(), O.psk_new(O.QPSK, None, 16, O.MATH_SHARED), O.psk_new(O.QPSK, None, 16, O.MATH_LIBM)
+    for blk in range(3):
+        iq = psk_test_signal(kind, 2048, seed=100 * blk + int(phase_deg), phase_deg=phase_deg, snr_db=20.0,
+                             timing_offset=3, uw_bpsk=uw, freq_offset=1e-5)
+        got = obj.demodulate(iq)
+        want = O.psk_demodulate(st, iq)
+        assert np.array_equal(got, want)
+        assert np.array_equal(got, O.psk_demodulate(st_libm, iq))
+        assert np.array_equal(obj.loop_state(), st.loop_state())
+        ncc = 1 if kind == O.BPSK else 4
+        assert list(obj.state().cc)[:ncc] == list(st.cc)[:ncc]
+
+
+def test_psk_bank_multichannel_device():
+    """Device layer: 70 channels (two waves, ragged) of QPSK and BPSK, two blocks each, vs the oracle."""
+    for kind in (O.BPSK, O.QPSK):
+        C_, nsym = 70, 512
+        n = nsym * 8
+        bank = device.PskBank(kind, C_, n)
+        sts = [O.psk_new(kind, math_mode=O.MATH_SHARED) for _ in range(C_)]
+        for blk in range(2):
+            sig = np.stack([psk_test_signal(kind, nsym, seed=1000 * blk + c, phase_deg=(37 * c) % 360, snr_db=18.0,
+                                            timing_offset=c % 8).reshape(n, 2) for c in range(C_)])
+            iq = torch.tensor(sig, device="cuda")
+            out = torch.zeros(C_, bank.n_dec, dtype=torch.uint8, device="cuda")
+            bank.demod(iq, out)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            hs = bank.host_states()
+            for c in range(C_):
+                want = O.psk_demodulate(sts[c], np.ascontiguousarray(sig[c].reshape(-1)))
+                assert np.array_equal(got[c].astype(np.float64), want), (kind, blk, c)
+                mine = np.frombuffer(bytes(hs[c])[: 8 * 24], dtype=np.float64)
+                assert np.array_equal(mine, sts[c].loop_state())
+
+
+def test_psk_modulators_vs_oracle():
+    """BPSK/QPSK::modulate incl. the byte-count memset (prior contents beyond len_mod/8 accumulate)."""
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2, 500).astype(np.uint8)
+    sym = rng.integers(0, 4, 500).astype(np.uint8)
+    prior = rng.uniform(-1, 1, 4000)
+    a, b = prior.copy(), prior.copy()
+    host.BPSK().modulate(bits, 500, a, 4000)
+    L.orc_bpsk_modulate(bits, 500, b, 4000)
+    assert np.array_equal(a, b)
+    ar, ai, br, bi = prior.copy(), prior[::-1].copy(), prior.copy(), prior[::-1].copy()
+    host.QPSK().modulate(sym, 500, ar, ai, 4000)
+    L.orc_qpsk_modulate(sym, 500, br, bi, 4000)
+    assert np.array_equal(ar, br) and np.array_equal(ai, bi)
