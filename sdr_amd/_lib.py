@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsdrx.so")
+LIB_PATH = os.environ.get("SDRX_LIB_PATH") or os.path.join(HERE, "libsdrx.so")  # override: experiments only
 
 REAL, IQ_SPLIT, IQ_INTERLEAVED = 0, 1, 2
 LPF, HPF, BPF = 0, 1, 2

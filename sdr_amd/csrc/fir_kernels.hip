@@ -18,6 +18,18 @@
 
 #include "../../include/sdrx_math.h"
 
+#include <array>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#ifndef SDRX_STAGE_UNR
+#define SDRX_STAGE_UNR 12
+#endif
+#ifndef SDRX_STEADY_UB
+#define SDRX_STEADY_UB 4
+#endif
+
 namespace sdrx {
 
 struct FirGeom {
@@ -38,7 +50,7 @@ struct FirGeom {
     unsigned Spad;         // Sp | 1: LDS elements between lane blocks
     unsigned magicSp;      // 0 => plain division
     unsigned n_staged;
-    unsigned q0, rem0;     // divmod(Wn - 1, Sp)
+    const int *offs;       // Wn byte offsets into a lane's LDS window, newest sample first
     double thr2;
 };
 
@@ -109,7 +121,7 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
     // Several loads per lane are issued before the first LDS write so that a CU keeps
     // tens of KB in flight; interior tiles (no history, no end of stream) skip the bounds tests.
     {
-        constexpr int UNR = 4;
+        constexpr int UNR = SDRX_STAGE_UNR; // all of a tile's loads are in flight before the first LDS write
         const long long span_last = b0 + (long long)((g.n_staged - 1) / g.Sp) * g.S + (g.n_staged - 1) % g.Sp;
         const bool interior = (b0 >= 0) && ((size_t)span_last < g.n);
         for (unsigned u0 = tid; u0 < g.n_staged; u0 += NT * UNR) {
@@ -131,7 +143,11 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
                         v[e].x = ((const double *)g.in0)[idx];
                         v[e].y = ((const double *)g.in1)[idx];
                     } else {
+#ifdef SDRX_ABL_NOLOAD /* diagnostic build: no global traffic for interior tiles */
+                        v[e] = make_double2((double)idx, 1.0);
+#else
                         v[e] = ((const double2 *)g.in0)[idx];
+#endif
                     }
                 } else {
                     v[e] = fetch_sample<LAYOUT>(g, chan, i);
@@ -151,11 +167,10 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
 
     const elem_t *lbase = lds + (size_t)tid * g.Spad;
     const double *__restrict__ taps = g.taps;
-    int q = (int)g.q0, rem = (int)g.rem0;
-    const int Sp = (int)g.Sp, Spad = (int)g.Spad;
+    const int *__restrict__ offs = g.offs; // same for every lane: scalar loads, no per-step address arithmetic
 
     auto step = [&](int j, bool guarded) {
-        elem_t x = lbase[q * Spad + rem];
+        elem_t x = *(const elem_t *)((const char *)lbase + offs[j]);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             int k = j - (R - 1 - r) * D;
@@ -169,13 +184,34 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
                 }
             }
         }
-        if (--rem < 0) { rem = Sp - 1; --q; }
     };
 
     const int jA = (R - 1) * D < T ? (R - 1) * D : T; // all accumulators live from here ...
     int j = 0;
+#ifdef SDRX_ABL_NOCOMPUTE /* diagnostic build: staging only, one LDS read keeps the tile live */
+    { elem_t x0 = lbase[0]; if constexpr (RAILS == 1) acc0[0] = x0; else { acc0[0] = x0.x; acc1[0] = x0.y; } j = Wn; }
+#endif
     for (; j < jA; j++) step(j, true);
-#pragma unroll 4
+    // steady state in blocks of UB steps: UB LDS reads back to back, then UB*R*RAILS multiply-adds
+    constexpr int UB = SDRX_STEADY_UB;
+    for (; j + UB <= T; j += UB) {
+        elem_t xs[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) xs[u] = *(const elem_t *)((const char *)lbase + offs[j + u]);
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const double h = taps[j + u - (R - 1 - r) * D];
+                if constexpr (RAILS == 1) {
+                    acc0[r] = mac<FMA>(acc0[r], xs[u], h);
+                } else {
+                    acc0[r] = mac<FMA>(acc0[r], xs[u].x, h);
+                    acc1[r] = mac<FMA>(acc1[r], xs[u].y, h);
+                }
+            }
+        }
+    }
     for (; j < T; j++) step(j, false);               // ... to here
     for (; j < Wn; j++) step(j, true);
 
@@ -243,7 +279,11 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
             double cj = aj * br + ar * bj;
             bool is_overlap = (tid == 0 && r == 0);
             if (!is_overlap && m >= 0 && (size_t)m < g.n_out) {
+#ifdef SDRX_ABL_NOEPI /* diagnostic build: no atan2 */
+                out[m] = cj + cr;
+#else
                 out[m] = sdrx_atan2(cj, cr);
+#endif
                 if ((size_t)m == g.n_out - 1) { st_out[2 * H] = ar; st_out[2 * H + 1] = aj; } // rtl_fm.c:543-544
             }
             pr = ar;
@@ -301,6 +341,30 @@ static fir_fn pick_kernel(int layout, int epi, bool fma, int R)
     if (layout == SDRX_IQ_SPLIT)
         return fma ? pick_epi<SDRX_IQ_SPLIT, true>(epi, R) : pick_epi<SDRX_IQ_SPLIT, false>(epi, R);
     return fma ? pick_epi<SDRX_IQ_INTERLEAVED, true>(epi, R) : pick_epi<SDRX_IQ_INTERLEAVED, false>(epi, R);
+}
+
+// Per-lane LDS window offsets for a tile geometry.  Tiny (Wn ints), created the first time a
+// geometry is used on a device and kept until the process ends; later calls allocate nothing.
+static const int *window_offsets_dev(unsigned Wn, unsigned Sp, unsigned Spad, unsigned elem)
+{
+    static std::mutex mu;
+    static std::map<std::array<unsigned, 5>, int *> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    const std::array<unsigned, 5> key = {(unsigned)dev, Wn, Sp, Spad, elem};
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    std::vector<int> h(Wn);
+    for (unsigned j = 0; j < Wn; j++) {
+        const unsigned c = Wn - 1 - j; // step j reads the sample c places after the window's oldest
+        h[j] = (int)(((c / Sp) * Spad + c % Sp) * elem);
+    }
+    int *d = nullptr;
+    if (hipMalloc((void **)&d, Wn * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), Wn * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    cache[key] = d;
+    return d;
 }
 
 static int env_int(const char *name, int dflt)
@@ -362,8 +426,6 @@ int launch_fir(const sdrx_fir_job *job, FirEpilogue epi)
         g.Sp = g.S < Wn ? g.S : Wn;
         g.Spad = g.Sp | 1u;
         g.n_staged = (NT - 1) * g.Sp + Wn;
-        g.q0 = (Wn - 1) / g.Sp;
-        g.rem0 = (Wn - 1) % g.Sp;
         const unsigned last = g.n_staged - 1;
         lds_bytes = ((size_t)(last / g.Sp) * g.Spad + last % g.Sp + 1) * elem;
         if (lds_bytes < 64) lds_bytes = 64;
@@ -373,6 +435,11 @@ int launch_fir(const sdrx_fir_job *job, FirEpilogue epi)
         if (lds_bytes <= lds_hard) break;
         set_error("FIR tile does not fit LDS: taps=%d decim=%u needs %zu bytes", T, D, lds_bytes);
         return SDRX_EUNSUPPORTED;
+    }
+    g.offs = window_offsets_dev((unsigned)T + (unsigned)(R - 1) * D, g.Sp, g.Spad, (unsigned)elem);
+    if (!g.offs) {
+        set_error("window offset table upload failed");
+        return SDRX_EHIP;
     }
     g.magicSp = (g.Sp < 2048 && g.n_staged < (1u << 20)) ? magic_u32(g.Sp) : 0;
     g.in0 = job->in0;
