@@ -94,8 +94,11 @@ SDRX_HD void sdrx_sincos(double x, double *s, double *c)
 
 /* ---- atan / atan2 ------------------------------------------------------- */
 
-/* atan(x) for x >= 0, finite */
-SDRX_HD double sdrx_atan_pos(double x)
+/* atan(ay/ax) for finite ay >= 0, ax > 0.  The classic 4-breakpoint reduction
+ * atan(x) = atan(c) + atan((x - c)/(1 + c x)), c in {0, 1/2, 1, 3/2, inf}, written on the
+ * PAIR (ay, ax) so that it costs one division instead of two, and with selects instead of
+ * branches so that a 64-lane wave does not execute every interval in turn. */
+SDRX_HD double sdrx_atan_ratio(double ay, double ax)
 {
     const double HI0 = 4.63647609000806093515e-01, HI1 = 7.85398163397448278999e-01,
                  HI2 = 9.82793723247329054082e-01, HI3 = 1.57079632679489655800e+00;
@@ -107,27 +110,19 @@ SDRX_HD double sdrx_atan_pos(double x)
                  A6 = 6.66107313738753120669e-02, A7 = -5.83357013379057348645e-02,
                  A8 = 4.97687799461593236017e-02, A9 = -3.65315727442169155270e-02,
                  A10 = 1.62858201153657823623e-02;
-    double hi, lo, t;
-    int red;
-    if (x >= 7.378697629483821e19) /* 2^66 */
-        return HI3 + LO3;
-    if (x < 0.4375) {
-        red = 0; hi = 0.0; lo = 0.0; t = x;
-    } else if (x < 0.6875) {
-        red = 1; hi = HI0; lo = LO0; t = (2.0 * x - 1.0) / (2.0 + x);
-    } else if (x < 1.1875) {
-        red = 1; hi = HI1; lo = LO1; t = (x - 1.0) / (x + 1.0);
-    } else if (x < 2.4375) {
-        red = 1; hi = HI2; lo = LO2; t = (x - 1.5) / (1.0 + 1.5 * x);
-    } else {
-        red = 1; hi = HI3; lo = LO3; t = -1.0 / x;
-    }
-    double z = t * t;
-    double w = z * z;
-    double s1 = z * (A0 + w * (A2 + w * (A4 + w * (A6 + w * (A8 + w * A10)))));
-    double s2 = w * (A1 + w * (A3 + w * (A5 + w * (A7 + w * A9))));
-    if (!red)
-        return t - t * (s1 + s2);
+    /* interval of ay/ax: [0,7/16) [7/16,11/16) [11/16,19/16) [19/16,39/16) [39/16,inf) */
+    const int i1 = ay >= 0.4375 * ax, i2 = ay >= 0.6875 * ax, i3 = ay >= 1.1875 * ax, i4 = ay >= 2.4375 * ax;
+    double num = ay, den = ax, hi = 0.0, lo = 0.0;
+    num = i1 ? (2.0 * ay - ax) : num;  den = i1 ? (2.0 * ax + ay) : den;  hi = i1 ? HI0 : hi;  lo = i1 ? LO0 : lo;
+    num = i2 ? (ay - ax) : num;        den = i2 ? (ay + ax) : den;        hi = i2 ? HI1 : hi;  lo = i2 ? LO1 : lo;
+    num = i3 ? (ay - 1.5 * ax) : num;  den = i3 ? (ax + 1.5 * ay) : den;  hi = i3 ? HI2 : hi;  lo = i3 ? LO2 : lo;
+    num = i4 ? -ax : num;              den = i4 ? ay : den;               hi = i4 ? HI3 : hi;  lo = i4 ? LO3 : lo;
+    const double t = num / den;
+    const double z = t * t;
+    const double w = z * z;
+    const double s1 = z * (A0 + w * (A2 + w * (A4 + w * (A6 + w * (A8 + w * A10)))));
+    const double s2 = w * (A1 + w * (A3 + w * (A5 + w * (A7 + w * A9))));
+    /* hi == lo == 0 in the first interval: hi - ((t*s - 0) - t) == t - t*s */
     return hi - ((t * (s1 + s2) - lo) - t);
 }
 
@@ -138,25 +133,25 @@ SDRX_HD double sdrx_atan2(double y, double x)
     const double PIO2 = 1.5707963267948965580e+00;
     if (x != x || y != y)
         return x + y;
-    int yneg = (y < 0.0) || (y == 0.0 && 1.0 / y < 0.0);
-    int xneg = (x < 0.0) || (x == 0.0 && 1.0 / x < 0.0);
+    const int yneg = (y < 0.0) || (y == 0.0 && 1.0 / y < 0.0);
+    const int xneg = (x < 0.0) || (x == 0.0 && 1.0 / x < 0.0);
     if (y == 0.0) {
         if (!xneg) return y;          /* +-0 */
         return yneg ? -PI : PI;
     }
     if (x == 0.0)
         return yneg ? -PIO2 : PIO2;
-    double ay = yneg ? -y : y;
-    double ax = xneg ? -x : x;
+    const double ay = yneg ? -y : y;
+    const double ax = xneg ? -x : x;
     double z;
-    int xinf = ax > 1.79769313486231570815e+308;
-    int yinf = ay > 1.79769313486231570815e+308;
+    const int xinf = ax > 1.79769313486231570815e+308;
+    const int yinf = ay > 1.79769313486231570815e+308;
     if (xinf || yinf) {
         if (xinf && yinf) z = 7.85398163397448278999e-01;
         else if (yinf) z = PIO2;
         else z = 0.0;
     } else {
-        z = sdrx_atan_pos(ay / ax);
+        z = sdrx_atan_ratio(ay, ax);
     }
     if (!xneg)
         return yneg ? -z : z;
