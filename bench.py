@@ -23,7 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from sdr_amd import _lib, device  # noqa: E402
+from sdr_amd import _lib, device, shard  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
@@ -167,10 +167,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = shard.max_over_ranks(dt, device=dev)
 
     if rank == 0:
         launch_s = ev_ms / 1e3 / args.steps  # HIP events on the launch stream, averaged over the timed steps
