@@ -51,7 +51,7 @@ def lpf_taps(T, Fs, Fx):
     return taps
 
 
-def cpu_baseline_cfg2(taps, D, sample_log2=26):
+def cpu_baseline_cfg2(taps, D, sample_log2=28):
     """The CPU restatement of the reference chain (oracle/, kind "port"), single thread, literal
     shift-register Filter (filt.cpp:248-273) on I and on Q, decimate, libm atan2 discriminator."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
