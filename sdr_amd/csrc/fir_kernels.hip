@@ -21,6 +21,7 @@
 #include <array>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #ifndef SDRX_STAGE_UNR
@@ -90,6 +91,15 @@ fetch_sample(const FirGeom &g, size_t chan, long long i)
     return v;
 }
 
+// f(integral_constant<int, I>) for I in [LO, HI): loop bounds that depend on I stay compile-time
+template <int LO, int HI, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (LO < HI) {
+        f(std::integral_constant<int, LO>{});
+        static_for<LO + 1, HI>(f);
+    }
+}
+
 template <bool FMA> __device__ __forceinline__ double mac(double acc, double x, double h)
 {
     if constexpr (FMA) return __builtin_fma(x, h, acc);
@@ -143,11 +153,7 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
                         v[e].x = ((const double *)g.in0)[idx];
                         v[e].y = ((const double *)g.in1)[idx];
                     } else {
-#ifdef SDRX_ABL_NOLOAD /* diagnostic build: no global traffic for interior tiles */
-                        v[e] = make_double2((double)idx, 1.0);
-#else
                         v[e] = ((const double2 *)g.in0)[idx];
-#endif
                     }
                 } else {
                     v[e] = fetch_sample<LAYOUT>(g, chan, i);
@@ -169,6 +175,12 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
     const double *__restrict__ taps = g.taps;
     const int *__restrict__ offs = g.offs; // same for every lane: scalar loads, no per-step address arithmetic
 
+    // accumulator r meets tap j - (R-1-r)*D at window step j: one base pointer per accumulator,
+    // so that a block of steps reads a contiguous run of taps per accumulator (one scalar load)
+    const double *tp[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) tp[r] = (const double *)((const char *)taps - (long long)(R - 1 - r) * D * 8);
+
     auto step = [&](int j, bool guarded) {
         elem_t x = *(const elem_t *)((const char *)lbase + offs[j]);
 #pragma unroll
@@ -186,13 +198,36 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
         }
     };
 
-    const int jA = (R - 1) * D < T ? (R - 1) * D : T; // all accumulators live from here ...
+    // Window step j multiplies sample (newest - j) into accumulator r with tap k = j - (R-1-r)*D.
+    // Head ramp, phase p (steps [p*D, (p+1)*D)): accumulators r >= R-1-p are live; tail ramp, phase p
+    // (steps [T + p*D, T + (p+1)*D)): r <= R-2-p.  Written out per phase, the live set is a
+    // compile-time range: no per-accumulator tests, and a phase's taps are D apart in one run.
+    auto ramp = [&](int j, auto lo, auto hi) {
+        elem_t x = *(const elem_t *)((const char *)lbase + offs[j]);
+#pragma unroll
+        for (int r = decltype(lo)::value; r <= decltype(hi)::value; r++) {
+            const double h = tp[r][j];
+            if constexpr (RAILS == 1) {
+                acc0[r] = mac<FMA>(acc0[r], x, h);
+            } else {
+                acc0[r] = mac<FMA>(acc0[r], x.x, h);
+                acc1[r] = mac<FMA>(acc1[r], x.y, h);
+            }
+        }
+    };
     int j = 0;
-#ifdef SDRX_ABL_NOCOMPUTE /* diagnostic build: staging only, one LDS read keeps the tile live */
-    { elem_t x0 = lbase[0]; if constexpr (RAILS == 1) acc0[0] = x0; else { acc0[0] = x0.x; acc1[0] = x0.y; } j = Wn; }
-#endif
-    for (; j < jA; j++) step(j, true);
-    // steady state in blocks of UB steps: UB LDS reads back to back, then UB*R*RAILS multiply-adds
+    const bool structured = (R - 1) * D <= T; // otherwise (a filter shorter than the lane's spread): tested steps
+    if (structured) {
+        static_for<0, R - 1>([&](auto p) {
+            for (int d = 0; d < D; d++, j++) ramp(j, std::integral_constant<int, R - 1 - decltype(p)::value>{},
+                                                  std::integral_constant<int, R - 1>{});
+        });
+    } else {
+        const int jA = (R - 1) * D < T ? (R - 1) * D : T;
+        for (; j < jA; j++) step(j, true);
+    }
+    // steady state (all accumulators live) in blocks of UB steps: UB LDS reads back to back, then
+    // UB*R*RAILS multiply-adds
     constexpr int UB = SDRX_STEADY_UB;
     for (; j + UB <= T; j += UB) {
         elem_t xs[UB];
@@ -202,7 +237,7 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
         for (int u = 0; u < UB; u++) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const double h = taps[j + u - (R - 1 - r) * D];
+                const double h = tp[r][j + u];
                 if constexpr (RAILS == 1) {
                     acc0[r] = mac<FMA>(acc0[r], xs[u], h);
                 } else {
@@ -212,8 +247,15 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
             }
         }
     }
-    for (; j < T; j++) step(j, false);               // ... to here
-    for (; j < Wn; j++) step(j, true);
+    for (; j < T; j++) step(j, false);
+    if (structured) {
+        static_for<0, R - 1>([&](auto p) {
+            for (int d = 0; d < D; d++, j++) ramp(j, std::integral_constant<int, 0>{},
+                                                  std::integral_constant<int, R - 2 - decltype(p)::value>{});
+        });
+    } else {
+        for (; j < Wn; j++) step(j, true);
+    }
 
     const long long m0 = m_tile0 + (long long)tid * R;
     const bool last_tile = (tile == g.tiles - 1);
@@ -279,11 +321,7 @@ __global__ void __launch_bounds__(256) fir_tile_kernel(const FirGeom g)
             double cj = aj * br + ar * bj;
             bool is_overlap = (tid == 0 && r == 0);
             if (!is_overlap && m >= 0 && (size_t)m < g.n_out) {
-#ifdef SDRX_ABL_NOEPI /* diagnostic build: no atan2 */
-                out[m] = cj + cr;
-#else
                 out[m] = sdrx_atan2(cj, cr);
-#endif
                 if ((size_t)m == g.n_out - 1) { st_out[2 * H] = ar; st_out[2 * H + 1] = aj; } // rtl_fm.c:543-544
             }
             pr = ar;
