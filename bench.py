@@ -78,8 +78,8 @@ def cpu_baseline_cfg2(taps, D, sample_log2=28):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
     ap.add_argument("--log2n", type=int, default=0, help="override samples per step (log2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

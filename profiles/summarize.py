@@ -14,7 +14,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 wl = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
-kname = sys.argv[3] if len(sys.argv) > 3 else "fir_tile_kernel"
+kname = sys.argv[3] if len(sys.argv) > 3 else "fir_"
 root = os.path.dirname(os.path.abspath(__file__))
 src = os.path.join(root, "..", "gpurun_out", "prof", tag)
 
