@@ -117,7 +117,7 @@ def main():
         step = lambda: chain.fir_fmdisc(x, out, fast_fma=args.fast_fma)  # noqa: E731
         units = nchan * n
         bytes_per_sample = 16.0 + 8.0 / D
-        kernel = "fir_tile_kernel<R=1, IQ_INTERLEAVED, EPI_DISC>"
+        kernel = "fir_systolic_kernel<D=10, IQ_INTERLEAVED, EPI_DISC>"
         cfg = {"workload": f"{wl}: Filter(LPF,64,2.4e6,1e5) on I,Q -> decimate 10 -> phase-difference discriminator",
                "channels_per_gpu": nchan, "samples_per_channel_per_step": n, "layout": "interleaved complex fp64",
                "parallelism": f"{n_gpus} independent stream set(s), no collective"}

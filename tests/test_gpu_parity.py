@@ -221,7 +221,7 @@ def _oracle_chain_disc(taps, re, im, D, hI, hQ, pre):
     return out[:m]
 
 
-@pytest.mark.parametrize("ds", [1, 8, 100])
+@pytest.mark.parametrize("ds", [1, 5, 8, 10, 12, 100])
 def test_chain_fir_am_host(ds):
     """BASELINE config 1: Filter(LPF,64,2e6,1e5) on I and Q, AM::demodulate(ds); streamed in chunks."""
     err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
@@ -229,7 +229,7 @@ def test_chain_fir_am_host(ds):
     re, im, _ = ook_iq(n, 1, ds=8)
     ch = host.Chain(taps, ds)
     hI, hQ = np.zeros(63), np.zeros(63)
-    step = 40000  # multiple of ds for every ds tested
+    step = 48000  # multiple of ds for every ds tested
     for k in range(0, n, step):
         r, i = re[k:k + step].copy(), im[k:k + step].copy()
         got = ch.fir_am(r, i)
@@ -237,10 +237,13 @@ def test_chain_fir_am_host(ds):
         assert np.array_equal(got, want), k
 
 
-@pytest.mark.parametrize("D,T", [(10, 64), (1, 64), (2, 33), (3, 64), (4, 129), (7, 20), (16, 64), (64, 64), (100, 64), (10, 1), (10, 2)])
+@pytest.mark.parametrize("D,T", [(10, 64), (1, 64), (2, 33), (3, 64), (4, 129), (7, 20), (16, 64), (64, 64), (100, 64), (10, 1), (10, 2),
+                                 (5, 33), (5, 61), (5, 64), (8, 7), (8, 64), (8, 97), (12, 64), (12, 100), (12, 144), (12, 145), (10, 120), (10, 121)])
 def test_chain_fir_fmdisc_host(D, T):
     """BASELINE config 2: LPF -> decimate by D -> phase-difference discriminator; every FIR register
-    blocking (R = 8, 4, 2, 1), gather tiles (D >= T) and the state carry across ragged chunks."""
+    blocking (R = 8, 4, 2, 1), gather tiles (D >= T), the systolic kernel (D in 5, 8, 10, 12: one stage,
+    whole and partial last stages, and filters long enough to fall back to workgroup tiles) and the
+    state carry across ragged chunks."""
     err, taps = O.fir_design(O.LPF, T, 2.4e6, 1.0e5)
     assert err == 0
     n = 200000
@@ -285,6 +288,41 @@ def test_chain_device_layouts_multichannel():
     torch.cuda.synchronize()
     for c in range(C_):
         assert np.array_equal(bits[c].cpu().numpy(), _oracle_chain_am(taps, res[c], ims[c], 1, np.zeros(63), np.zeros(63)))
+
+
+@pytest.mark.parametrize("D", [5, 8, 10, 12])
+def test_decimating_fir_store_all_layouts(D):
+    """sdrx_fir_dev with decimation (Filter on each rail, then decimate<T>, Resample.h:33-52): real,
+    split and interleaved inputs through the systolic kernel, 3 channels, two calls with carried state;
+    samples bit-identical to the oracle's Filter + decimate."""
+    T = 64
+    err, taps = O.fir_design(O.BPF, T, 2.4e6, 1.0e5, 3.0e5)
+    assert err == 0
+    C_, n = 3, 30011
+    res, ims = zip(*[radio_iq(n, 70 + c) for c in range(C_)])
+    re = torch.tensor(np.stack(res), device="cuda")
+    im = torch.tensor(np.stack(ims), device="cuda")
+    iq = torch.stack([re, im], dim=-1).contiguous()
+    n_out = (n + D - 1) // D
+
+    for x, rails in ((re, 1), ((re, im), 2), (iq, 2)):
+        ch = device.FirChain(taps, nchan=C_, decim=D)
+        outs = []
+        for _ in range(2):
+            o0 = torch.zeros(C_, n_out, dtype=torch.float64, device="cuda")
+            o1 = torch.zeros(C_, n_out, dtype=torch.float64, device="cuda") if rails == 2 else None
+            ch.fir(x, o0, o1)
+            outs.append((o0, o1))
+        torch.cuda.synchronize()
+        for c in range(C_):
+            fi, fq = O.Fir(O.BPF, T, 2.4e6, 1.0e5, 3.0e5), O.Fir(O.BPF, T, 2.4e6, 1.0e5, 3.0e5)
+            for o0, o1 in outs:
+                # the second call starts at sample n of the doubled stream: its decimation phase restarts at 0
+                yi = fi.execute(res[c], fast=True)[::D]
+                assert np.array_equal(o0[c].cpu().numpy(), yi), (D, rails, c)
+                if rails == 2:
+                    yq = fq.execute(ims[c], fast=True)[::D]
+                    assert np.array_equal(o1[c].cpu().numpy(), yq), (D, rails, c)
 
 
 def test_fast_fma_within_tolerance():
