@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 from sdr_amd import _lib, device, shard  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+F64_PEAK_TFLOPS = 78.6  # dense fp64 MFMA peak = fp64 vector FMA peak on MI355X (AMD datasheet: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
 
 
 def synth_fm_stream(n, seed, dev, fs=2.4e6, dev_hz=75e3, tone=1000.0, amp=100.0):
@@ -80,10 +81,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--log2n", type=int, default=0, help="override samples per step (log2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--fast-fma", action="store_true")
+    ap.add_argument("--mfma", action="store_true", help="cfg5: fp64 MFMA Toeplitz formulation (fast mode 2)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,6 +137,26 @@ def main():
         cfg = {"workload": "cfg1: Filter(LPF,64,2e6,1e5) on I,Q -> AM envelope threshold (ds=1)",
                "channels_per_gpu": 1, "samples_per_channel_per_step": n, "layout": "interleaved complex fp64",
                "parallelism": f"{n_gpus} independent stream(s), no collective"}
+    elif wl == "cfg5":
+        T, Fs = 1024, 2.0e6
+        taps = np.zeros(T)
+        assert _lib.lib().sdrx_fir_design(_lib.LPF, 0, T, Fs, Fs / 20, 0.0, 4096, taps.ctypes.data) == 0
+        nchan, n = 1024, 1 << (args.log2n or 18)
+        g = torch.Generator(device=dev).manual_seed(5 + rank)
+        x = torch.randint(-127, 128, (nchan, n), generator=g, device=dev).to(torch.float64)
+        chain = device.FirChain(taps, nchan=nchan, decim=1, device=dev)
+        out = torch.zeros(nchan, n, dtype=torch.float64, device=dev)
+        mode = 2 if args.mfma else (1 if args.fast_fma else 0)
+        step = lambda: chain.fir(x, out, fast_fma=mode)  # noqa: E731
+        units = nchan * n
+        bytes_per_sample = 16.0
+        flop_per_sample = 2.0 * T
+        kernel = "fir_mfma_kernel<NB=4>" if mode == 2 else "fir_tile_kernel<R=8, REAL, EPI_STORE>"
+        cfg = {"workload": "cfg5: 1024-tap Filter(LPF) bank, one real rail per channel, "
+                           + ("fp64 MFMA Toeplitz formulation (fma chain)", "VALU convolution (fma chain)",
+                              "VALU convolution (separate multiply and add roundings, as the CPU)")[2 - mode if mode else 2],
+               "channels_per_gpu": nchan, "samples_per_channel_per_step": n, "layout": "real fp64",
+               "parallelism": f"{n_gpus} x {nchan} independent channels, no collective"}
     else:  # cfg3
         nchan, n = 1 << 14, 1 << ((args.log2n or 26) - 14)
         g = torch.Generator(device=dev).manual_seed(7 + rank)
@@ -179,6 +201,14 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        roof = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_sample": bytes_per_sample, "launch_ms": launch_s * 1e3}
+        if wl == "cfg5":  # 2048 flop per 16 B: compute bound; priced against the dense fp64 matrix peak (= the vector FMA peak)
+            tf = flop_per_sample * units / launch_s / 1e12
+            roof = {"bound": "mfma", "kernel": kernel, "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / F64_PEAK_TFLOPS, "traffic": traffic, "algorithmic_flop_per_sample": flop_per_sample,
+                    "launch_ms": launch_s * 1e3}
         res = {
             "metric": "Msamples/sec through FIR+demod chain",
             "value": n_gpus * units * args.steps / dt / 1e6,
@@ -188,9 +218,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": cfg,
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_sample": bytes_per_sample, "launch_ms": launch_s * 1e3},
+            "roofline": roof,
         }
         if n_gpus == 1 and not args.no_cpu and wl == "cfg2":
             res["cpu_baseline"] = cpu_baseline_cfg2(taps, 10)

@@ -60,7 +60,7 @@ const char *sdrx_version(void);
 
 /*
  * One FIR (+ fused epilogue) job over `nchan` independent channels.
- *   y[c][m] = sum_{k=0}^{T-1} x[c][m*D + phase - k] * h[k]      (k ascending: filt.cpp:261-262)
+ *   y[c][m] = sum_{k=0}^{T-1} x[c][m*D - k] * h[k]              (k ascending: filt.cpp:261-262)
  * x[c][i<0] comes from the channel's carried history (Filter's shift register, filt.cpp:256-259).
  * State per channel (doubles): hist0[T-1] (x[-1], x[-2], ...), hist1[T-1] (second rail), pre[2].
  * state_in and state_out must be different buffers (a launch reads one and writes the other);
@@ -68,7 +68,11 @@ const char *sdrx_version(void);
  */
 typedef struct sdrx_fir_job {
     int layout;               /* SDRX_REAL / SDRX_IQ_SPLIT / SDRX_IQ_INTERLEAVED */
-    int fast_fma;             /* 0: mul then add like the CPU reference (bit-exact); 1: fused FMA (<=1e-12 rel.) */
+    int fast_fma;             /* 0: multiply then add, two roundings, like the CPU reference (bit-exact with it);
+                                 1: acc = fma(x, h, acc), k ascending (<= 1e-12 of sum|h||x| from mode 0);
+                                 2: the same fma chain on the fp64 matrix cores (sdrx_fir_dev, decim 1,
+                                    num_taps >= 32; other shapes run as mode 1).  Bit-identical to mode 1
+                                    for finite inputs */
     const void *in0, *in1;    /* device */
     size_t n;                 /* input samples per channel */
     size_t nchan;

@@ -84,6 +84,26 @@ void orc_fir_execute_fast(const double *taps, int T, double *hist, double *buf, 
     free(x);
 }
 
+/* The same sum with one rounding per term: result = fma(x[n-k], h[k], result), k ascending.  NOT what
+ * filt.cpp computes (it rounds the product and the sum separately); this is the definition of the
+ * library's opt-in fast modes (sdrx_fir_job.fast_fma = 1: VALU fma chain, 2: fp64 MFMA, which on gfx950
+ * is the same chain), so that those modes can be checked bit for bit too. */
+void orc_fir_execute_fma(const double *taps, int T, double *hist, double *buf, size_t n)
+{
+    size_t H = (size_t)(T - 1);
+    double *x = (double *)malloc((H + n) * sizeof(double));
+    for (size_t k = 0; k < H; k++) x[H - 1 - k] = hist[k];
+    memcpy(x + H, buf, n * sizeof(double));
+    for (size_t s = 0; s < n; s++) {
+        const double *p = x + H + s;
+        double result = 0;
+        for (int i = 0; i < T; i++) result = fma(p[-i], taps[i], result);
+        buf[s] = result;
+    }
+    for (size_t k = 0; k < H; k++) hist[k] = x[H + n - 1 - k];
+    free(x);
+}
+
 /* ---------------------------------------------------------------------- AM */
 
 size_t orc_raw_upsample(const double *in, size_t in_len, double *out, size_t out_len, double ratio)

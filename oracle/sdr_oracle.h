@@ -41,6 +41,8 @@ void orc_fir_execute(const double *taps, int num_taps, double *sr, double *buf, 
 /* Same arithmetic (same sums, same order) without the O(T) register shuffle; hist[T-1]
  * holds x[-1], x[-2], ... (newest first) and is updated.  Used for large-N checks. */
 void orc_fir_execute_fast(const double *taps, int num_taps, double *hist, double *buf, size_t n);
+/* fused variant (one rounding per term): the definition of the library's fast_fma modes, not of filt.cpp */
+void orc_fir_execute_fma(const double *taps, int num_taps, double *hist, double *buf, size_t n);
 
 /* ---- AM (streams/AM.h) ---- */
 void orc_am_modulate(const uint8_t *bits, size_t len, double *out_real, size_t len_mod); /* AM.h:41-54 */

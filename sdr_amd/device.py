@@ -52,7 +52,7 @@ class FirChain:
     def _job(self, layout, in0, in1, n, in_pitch, out0, out1, out_pitch, fast_fma, n_out):
         j = _lib.FirJob()
         j.layout = layout
-        j.fast_fma = 1 if fast_fma else 0
+        j.fast_fma = int(fast_fma)  # False/0 exact, True/1 fma chain, 2 fp64 MFMA
         j.in0, j.in1 = _ptr(in0), _ptr(in1)
         j.n, j.nchan, j.in_pitch = n, self.nchan, in_pitch
         j.taps, j.num_taps, j.decim = _ptr(self.taps), self.T, self.decim

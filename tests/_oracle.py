@@ -68,6 +68,8 @@ def lib():
     L.orc_fir_execute.restype = None
     L.orc_fir_execute_fast.argtypes = [_f64, C.c_int, _f64, _f64, _sz]
     L.orc_fir_execute_fast.restype = None
+    L.orc_fir_execute_fma.argtypes = [_f64, C.c_int, _f64, _f64, _sz]
+    L.orc_fir_execute_fma.restype = None
     L.orc_am_modulate.argtypes = [_u8, _sz, _f64, _sz]
     L.orc_am_modulate.restype = None
     L.orc_am_demodulate.argtypes = [_f64, _f64, _u8, _sz, _sz]
@@ -135,6 +137,14 @@ class Fir:
         self.err, self.taps = fir_design(ftype, ntaps, Fs, Fx, Fu, max_taps)
         self.T = int(ntaps)
         self.sr = np.zeros(max(self.T, 1), dtype=np.float64)
+
+    def execute_fma(self, buf):
+        """fused-chain variant (definition of the fast_fma modes); history carried like execute(fast=True)"""
+        buf = np.ascontiguousarray(buf, dtype=np.float64).copy()
+        hist = self.sr[: self.T - 1].copy() if self.T > 1 else np.zeros(1)
+        lib().orc_fir_execute_fma(self.taps, self.T, hist, buf, buf.size)
+        self.sr[: self.T - 1] = hist[: self.T - 1]
+        return buf
 
     def execute(self, buf, fast=False):
         buf = np.ascontiguousarray(buf, dtype=np.float64).copy()

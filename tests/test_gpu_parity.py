@@ -325,6 +325,42 @@ def test_decimating_fir_store_all_layouts(D):
                     assert np.array_equal(o1[c].cpu().numpy(), yq), (D, rails, c)
 
 
+@pytest.mark.parametrize("T", [32, 64, 129, 1024])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fast_modes_are_the_fused_chain_bit_for_bit(mode, T):
+    """fast_fma = 1 (VALU fma chain) and 2 (fp64 MFMA Toeplitz kernel) both compute
+    acc = fma(x[n-k], h[k], acc), k ascending: checked bit for bit against the oracle's fused variant,
+    real / split / interleaved layouts, 3 channels, ragged length, two calls with carried history."""
+    err, taps = O.fir_design(O.LPF, T, 2.0e6, 1.0e5, max_taps=4096)
+    assert err == 0
+    C_, n = 3, 5000 + 7
+    res, ims = zip(*[radio_iq(n, 90 + c) for c in range(C_)])
+    re = torch.tensor(np.stack(res), device="cuda")
+    im = torch.tensor(np.stack(ims), device="cuda")
+    iq = torch.stack([re, im], dim=-1).contiguous()
+    for x, rails, inter_out in ((re, 1, False), ((re, im), 2, False), (iq, 2, False), (iq, 2, True)):
+        ch = device.FirChain(taps, nchan=C_, decim=1)
+        outs = []
+        for _ in range(2):
+            if inter_out:
+                o0 = torch.zeros(C_, n, 2, dtype=torch.float64, device="cuda")
+                ch.fir(x, o0, None, fast_fma=mode)
+                outs.append((o0[..., 0], o0[..., 1]))
+            else:
+                o0 = torch.zeros(C_, n, dtype=torch.float64, device="cuda")
+                o1 = torch.zeros(C_, n, dtype=torch.float64, device="cuda") if rails == 2 else None
+                ch.fir(x, o0, o1, fast_fma=mode)
+                outs.append((o0, o1))
+        torch.cuda.synchronize()
+        for c in range(C_):
+            fi = O.Fir(O.LPF, T, 2.0e6, 1.0e5, max_taps=4096)
+            fq = O.Fir(O.LPF, T, 2.0e6, 1.0e5, max_taps=4096)
+            for o0, o1 in outs:
+                assert np.array_equal(o0[c].cpu().numpy(), fi.execute_fma(res[c])), (mode, T, rails, c)
+                if rails == 2:
+                    assert np.array_equal(o1[c].cpu().numpy(), fq.execute_fma(ims[c])), (mode, T, rails, c)
+
+
 def test_fast_fma_within_tolerance():
     """fast_fma = 1 fuses multiply-add: not bit-exact; bound |err| <= 1e-12 * sum|h||x| (north_star's fp64 tolerance)."""
     err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
