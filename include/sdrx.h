@@ -36,6 +36,10 @@ extern "C" {
 #define SDRX_ENOMEM (-4)
 
 /* sample layouts at the device boundary */
+/* sample type of a device-layer FIR job */
+#define SDRX_F64 0
+#define SDRX_F32 1
+
 #define SDRX_REAL 0           /* one rail: in0 = T[n] */
 #define SDRX_IQ_SPLIT 1       /* in0 = re[n], in1 = im[n]  (AM.h:63, FM.h:112, rtlsdr_receiver.cpp:1994-1995) */
 #define SDRX_IQ_INTERLEAVED 2 /* in0 = {re,im}[n] = std::complex<double>[n] (Common_Deffinitions.h:12-13, BBP_Block.h:14) */
@@ -77,16 +81,18 @@ typedef struct sdrx_fir_job {
     size_t n;                 /* input samples per channel */
     size_t nchan;
     size_t in_pitch;          /* samples between consecutive channels */
-    const double *taps;       /* device, num_taps doubles */
+    const void *taps;         /* device, num_taps samples of the job's dtype */
     int num_taps;
     unsigned decim;           /* D >= 1 */
-    const double *state_in;   /* device, nchan * state_pitch doubles */
-    double *state_out;
+    const void *state_in;     /* device, nchan * state_pitch samples of the job's dtype */
+    void *state_out;
     size_t state_pitch;
     void *out0, *out1;        /* device; meaning depends on the entry point */
     size_t out_pitch;         /* output elements between channels */
     size_t n_out;             /* 0 = ceil(n / D); otherwise exactly this many outputs per channel */
     void *stream;             /* hipStream_t, NULL = default stream */
+    int dtype;                /* SDRX_F64 (0, default): the reference's fp64; SDRX_F32: the fp32 twins -- float samples,
+                                 taps, state and outputs, fused multiply-add, checked to 1e-5 relative */
 } sdrx_fir_job;
 
 /* Filter::execute (filt.cpp:267-273) on 1 rail (out0) or on I and Q (out0, out1), optionally

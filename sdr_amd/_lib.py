@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("SDRX_LIB_PATH") or os.path.join(HERE, "libsdrx.so")  
 REAL, IQ_SPLIT, IQ_INTERLEAVED = 0, 1, 2
 LPF, HPF, BPF = 0, 1, 2
 BPSK, QPSK = 0, 1
+F64, F32 = 0, 1
 REF_MAX_TAPS = 1000
 
 _vp = C.c_void_p
@@ -25,7 +26,7 @@ class FirJob(C.Structure):
         ("taps", _vp), ("num_taps", C.c_int), ("decim", C.c_uint),
         ("state_in", _vp), ("state_out", _vp), ("state_pitch", _sz),
         ("out0", _vp), ("out1", _vp), ("out_pitch", _sz), ("n_out", _sz),
-        ("stream", _vp),
+        ("stream", _vp), ("dtype", C.c_int),
     ]
 
 

@@ -33,6 +33,7 @@ inline unsigned magic_u32(unsigned d) { return (unsigned)((0x100000000ULL + d - 
 // launchers implemented in fir_kernels.hip
 enum FirEpilogue { EPI_STORE = 0, EPI_AM = 1, EPI_DISC = 2 };
 int launch_fir(const sdrx_fir_job *job, FirEpilogue epi);
+int launch_fir_mfma(const sdrx_fir_job *job, size_t n_out); // fir_mfma.hip: fast mode 2, fp64 only
 
 // demod_kernels.hip
 int launch_am_demod(const double *re, const double *im, uint8_t *out, size_t n, size_t ds, hipStream_t s);

@@ -29,16 +29,20 @@ class FirChain:
     Mirrors Filter objects on I and Q (filt.cpp:236-273) per channel: hist = the shift register,
     pre = the discriminator's previous sample (rtl_fm.c:523,543-544)."""
 
-    def __init__(self, taps, nchan=1, decim=1, device="cuda"):
+    def __init__(self, taps, nchan=1, decim=1, device="cuda", dtype=torch.float64):
+        """dtype = torch.float64: the reference's arithmetic; torch.float32: the fp32 twins (float samples,
+        taps, state and outputs)."""
         self.L = _lib.lib()
+        assert dtype in (torch.float64, torch.float32)
+        self.dtype = dtype
         taps = np.ascontiguousarray(taps, dtype=np.float64)
         self.T = int(taps.size)
         self.decim = int(decim)
         self.nchan = int(nchan)
         self.device = torch.device(device)
-        self.taps = torch.from_numpy(taps).to(self.device)
+        self.taps = torch.from_numpy(taps).to(self.device).to(dtype)
         self.pitch = int(self.L.sdrx_fir_state_doubles(self.T))
-        self.state = [torch.zeros(self.nchan, self.pitch, dtype=torch.float64, device=self.device) for _ in range(2)]
+        self.state = [torch.zeros(self.nchan, self.pitch, dtype=dtype, device=self.device) for _ in range(2)]
         self.cur = 0
 
     def reset(self):
@@ -60,6 +64,7 @@ class FirChain:
         j.state_pitch = self.pitch
         j.out0, j.out1, j.out_pitch, j.n_out = _ptr(out0), _ptr(out1), out_pitch, n_out
         j.stream = _stream()
+        j.dtype = _lib.F32 if self.dtype == torch.float32 else _lib.F64
         return j
 
     def _run(self, fn, name, layout, in0, in1, n, in_pitch, out0, out1, out_pitch, fast_fma=False, n_out=0):
@@ -68,13 +73,12 @@ class FirChain:
         self.cur ^= 1
 
     # x: (nchan, n, 2) interleaved complex f64, or (re, im) tuple of (nchan, n), or a single real (nchan, n)
-    @staticmethod
-    def _inputs(x):
+    def _inputs(self, x):
         if isinstance(x, (tuple, list)):
             re, im = x
-            assert re.dtype == torch.float64 and re.is_contiguous() and im.is_contiguous()
+            assert re.dtype == self.dtype == im.dtype and re.is_contiguous() and im.is_contiguous()
             return _lib.IQ_SPLIT, re, im, re.shape[-1], re.shape[-1]
-        assert x.dtype == torch.float64 and x.is_contiguous()
+        assert x.dtype == self.dtype and x.is_contiguous()
         if x.dim() == 3 and x.shape[-1] == 2:
             return _lib.IQ_INTERLEAVED, x, None, x.shape[1], x.shape[1]
         return _lib.REAL, x, None, x.shape[-1], x.shape[-1]

@@ -361,6 +361,62 @@ def test_fast_modes_are_the_fused_chain_bit_for_bit(mode, T):
                     assert np.array_equal(o1[c].cpu().numpy(), fq.execute_fma(ims[c])), (mode, T, rails, c)
 
 
+# =============================================================================== fp32 twins
+
+@pytest.mark.parametrize("D,T", [(1, 64), (4, 129), (10, 64), (8, 64), (5, 33), (12, 100), (3, 64), (100, 64)])
+def test_f32_twins_within_1e5(D, T):
+    """dtype = SDRX_F32 (float samples, taps, state, outputs; fused multiply-add).  There is no fp32
+    reference: the checker is the fp64 CPU path, tolerance north_star's 1e-5 relative --
+    filtered samples: |err| <= 1e-5 * sum|h||x|; discriminator angle: <= 1e-5 * pi (mod 2 pi) on a
+    constant-envelope FM signal; AM bits: equal wherever the fp64 envelope is not within 1e-4 of the
+    threshold.  Two calls, history carried; split and interleaved layouts."""
+    err, taps = O.fir_design(O.LPF, T, 2.4e6, 1.0e5)
+    assert err == 0
+    C_, n = 2, 40000 + 3
+    res, ims = zip(*[fm_iq(n, seed=60 + c) for c in range(C_)])
+    re64, im64 = np.stack(res), np.stack(ims)
+    re = torch.tensor(re64, device="cuda", dtype=torch.float32)
+    im = torch.tensor(im64, device="cuda", dtype=torch.float32)
+    iq = torch.stack([re, im], dim=-1).contiguous()
+    n_out = (n + D - 1) // D
+    scale_i = [np.convolve(np.abs(np.concatenate([r, r])), np.abs(taps))[:2 * n] + 1e-30 for r in res]
+    scale_q = [np.convolve(np.abs(np.concatenate([q, q])), np.abs(taps))[:2 * n] + 1e-30 for q in ims]
+    for x in ((re, im), iq):
+        ch = device.FirChain(taps, nchan=C_, decim=D, dtype=torch.float32)
+        cd = device.FirChain(taps, nchan=C_, decim=D, dtype=torch.float32)
+        ca = device.FirChain(taps, nchan=C_, decim=D, dtype=torch.float32)
+        got = []
+        for _ in range(2):
+            o0 = torch.zeros(C_, n_out, dtype=torch.float32, device="cuda")
+            o1 = torch.zeros(C_, n_out, dtype=torch.float32, device="cuda")
+            ang = torch.zeros(C_, n_out, dtype=torch.float32, device="cuda")
+            bits = torch.zeros(C_, n_out, dtype=torch.uint8, device="cuda")
+            ch.fir(x, o0, o1)
+            cd.fir_fmdisc(x, ang)
+            ca.fir_am(x, bits)
+            got.append((o0.cpu().numpy(), o1.cpu().numpy(), ang.cpu().numpy(), bits.cpu().numpy()))
+        for c in range(C_):
+            fi, fq = O.Fir(O.LPF, T, 2.4e6, 1.0e5), O.Fir(O.LPF, T, 2.4e6, 1.0e5)
+            pre = np.zeros(2)
+            for call, (o0, o1, ang, bits) in enumerate(got):
+                yi = fi.execute(res[c], fast=True)[::D]
+                yq = fq.execute(ims[c], fast=True)[::D]
+                si = scale_i[c][call * n:(call + 1) * n][::D]
+                sq = scale_q[c][call * n:(call + 1) * n][::D]
+                assert np.max(np.abs(o0[c] - yi) / si) <= 1e-5, (D, T, c, call)
+                assert np.max(np.abs(o1[c] - yq) / sq) <= 1e-5, (D, T, c, call)
+                want = np.zeros(n_out)
+                L.orc_fm_discriminator(yi.copy(), yq.copy(), n_out, pre, want, O.MATH_LIBM)
+                mag = np.hypot(yi, yq)
+                ok = mag > 10.0  # where the filtered vector is tiny its angle is ill-conditioned in any precision
+                ok[1:] &= mag[:-1] > 10.0
+                d = np.angle(np.exp(1j * (ang[c] - want)))
+                assert np.max(np.abs(d[ok])) <= 1e-5 * np.pi, (D, T, c, call, np.max(np.abs(d[ok])))
+                env = np.sqrt(yi * yi + yq * yq)
+                sure = np.abs(env - 80.0) > 1e-4 * 80.0
+                assert np.array_equal(bits[c][sure], (env >= 80.0).astype(np.uint8)[sure]), (D, T, c, call)
+
+
 def test_fast_fma_within_tolerance():
     """fast_fma = 1 fuses multiply-add: not bit-exact; bound |err| <= 1e-12 * sum|h||x| (north_star's fp64 tolerance)."""
     err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
