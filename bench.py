@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--log2n", type=int, default=0, help="override samples per step (log2)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="f32: the fp32 twins (cfg1, cfg2, cfg4)")
+    ap.add_argument("--ingest", default="fp", choices=["fp", "u8"],
+                    help="u8: the input is the radio's raw uint8 {I,Q} stream, converted on load (cfg1, cfg2, cfg4)")
     ap.add_argument("--fast-fma", action="store_true")
     ap.add_argument("--mfma", action="store_true", help="cfg5: fp64 MFMA Toeplitz formulation (fast mode 2)")
     args = ap.parse_args()
@@ -108,8 +110,14 @@ def main():
     cfg = {}
     f32 = args.dtype == "f32"
     tdt = torch.float32 if f32 else torch.float64
-    if f32 and wl not in ("cfg1", "cfg2", "cfg4"):
-        raise SystemExit("--dtype f32 exists for cfg1, cfg2 and cfg4")
+    u8 = args.ingest == "u8"
+    if (f32 or u8) and wl not in ("cfg1", "cfg2", "cfg4"):
+        raise SystemExit("--dtype f32 / --ingest u8 exist for cfg1, cfg2 and cfg4")
+    in_bytes = 2.0 if u8 else (8.0 if f32 else 16.0)
+    lay = "raw uint8 {I,Q}, converted on load (byte - 127)" if u8 else "interleaved complex " + ("fp32" if f32 else "fp64")
+
+    def as_input(x):  # synthetic samples are integers in [-127, 127]: byte = x + 127
+        return (x + 127.0).to(torch.uint8).contiguous() if u8 else x.to(tdt)
     if wl in ("cfg2", "cfg4"):
         D, T, Fs = 10, 64, 2.4e6
         taps = lpf_taps(T, Fs, 1.0e5)
@@ -119,31 +127,31 @@ def main():
         else:
             nchan, n = 1024, 1 << (args.log2n or 18)
             x = synth_fm_stream(nchan * n, 1000 + rank, dev).view(nchan, n, 2)
-        x = x.to(tdt)
+        x = as_input(x)
         chain = device.FirChain(taps, nchan=nchan, decim=D, device=dev, dtype=tdt)
         out = torch.zeros(nchan, chain.n_out(n), dtype=tdt, device=dev)
         step = lambda: chain.fir_fmdisc(x, out, fast_fma=args.fast_fma)  # noqa: E731
         units = nchan * n
-        bytes_per_sample = (8.0 + 4.0 / D) if f32 else (16.0 + 8.0 / D)
+        bytes_per_sample = in_bytes + (4.0 if f32 else 8.0) / D
         kernel = "fir_systolic_kernel<D=10, IQ_INTERLEAVED, EPI_DISC>"
         cfg = {"workload": f"{wl}: Filter(LPF,64,2.4e6,1e5) on I,Q -> decimate 10 -> phase-difference discriminator",
                "channels_per_gpu": nchan, "samples_per_channel_per_step": n,
-               "layout": "interleaved complex " + ("fp32" if f32 else "fp64"),
+               "layout": lay,
                "parallelism": f"{n_gpus} independent stream set(s), no collective"}
     elif wl == "cfg1":
         T, Fs = 64, 2.0e6
         taps = lpf_taps(T, Fs, 1.0e5)
         nchan, n = 1, 1 << (args.log2n or 28)
-        x = synth_fm_stream(n, 1000 + rank, dev).to(tdt)
+        x = as_input(synth_fm_stream(n, 1000 + rank, dev))
         chain = device.FirChain(taps, nchan=nchan, decim=1, device=dev, dtype=tdt)
         out = torch.zeros(nchan, n, dtype=torch.uint8, device=dev)
         step = lambda: chain.fir_am(x, out, fast_fma=args.fast_fma)  # noqa: E731
         units = n
-        bytes_per_sample = 9.0 if f32 else 17.0
+        bytes_per_sample = in_bytes + 1.0
         kernel = "fir_tile_kernel<R=8, IQ_INTERLEAVED, EPI_AM>"
         cfg = {"workload": "cfg1: Filter(LPF,64,2e6,1e5) on I,Q -> AM envelope threshold (ds=1)",
                "channels_per_gpu": 1, "samples_per_channel_per_step": n,
-               "layout": "interleaved complex " + ("fp32" if f32 else "fp64"),
+               "layout": lay,
                "parallelism": f"{n_gpus} independent stream(s), no collective"}
     elif wl == "cfg5":
         T, Fs = 1024, 2.0e6
@@ -228,7 +236,7 @@ def main():
             "config": cfg,
             "roofline": roof,
         }
-        if n_gpus == 1 and not args.no_cpu and wl == "cfg2" and not f32:
+        if n_gpus == 1 and not args.no_cpu and wl == "cfg2" and not f32 and not u8:
             res["cpu_baseline"] = cpu_baseline_cfg2(taps, 10)
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -43,6 +43,9 @@ extern "C" {
 #define SDRX_REAL 0           /* one rail: in0 = T[n] */
 #define SDRX_IQ_SPLIT 1       /* in0 = re[n], in1 = im[n]  (AM.h:63, FM.h:112, rtlsdr_receiver.cpp:1994-1995) */
 #define SDRX_IQ_INTERLEAVED 2 /* in0 = {re,im}[n] = std::complex<double>[n] (Common_Deffinitions.h:12-13, BBP_Block.h:14) */
+#define SDRX_IQ_U8 3          /* in0 = uint8_t {I,Q}[n]: the RTL-SDR wire format, converted on load (device layer only) */
+#define SDRX_U8_SIGNED_CHAR 1 /* read bytes as signed char, like Baseband_Stream::load_buffer(char*, ...) does on x86 */
+#define SDRX_U8_ROTATE90 2    /* apply rotate_90 (Baseband_Stream.cpp:82-101, rtl_fm.c:282-301) before converting */
 
 /* Filter::filterType, filt.h:131 */
 #define SDRX_LPF 0
@@ -71,7 +74,7 @@ const char *sdrx_version(void);
  * state_pitch >= 2*(T-1)+2.  Outputs never alias inputs.
  */
 typedef struct sdrx_fir_job {
-    int layout;               /* SDRX_REAL / SDRX_IQ_SPLIT / SDRX_IQ_INTERLEAVED */
+    int layout;               /* SDRX_REAL / SDRX_IQ_SPLIT / SDRX_IQ_INTERLEAVED / SDRX_IQ_U8 */
     int fast_fma;             /* 0: multiply then add, two roundings, like the CPU reference (bit-exact with it);
                                  1: acc = fma(x, h, acc), k ascending (<= 1e-12 of sum|h||x| from mode 0);
                                  2: the same fma chain on the fp64 matrix cores (sdrx_fir_dev, decim 1,
@@ -93,6 +96,9 @@ typedef struct sdrx_fir_job {
     void *stream;             /* hipStream_t, NULL = default stream */
     int dtype;                /* SDRX_F64 (0, default): the reference's fp64; SDRX_F32: the fp32 twins -- float samples,
                                  taps, state and outputs, fused multiply-add, checked to 1e-5 relative */
+    int u8_flags;             /* SDRX_IQ_U8 only: SDRX_U8_SIGNED_CHAR | SDRX_U8_ROTATE90 */
+    double u8_bias;           /* SDRX_IQ_U8 only: x = (T)byte - u8_bias (127: rtlsdr_receiver.cpp:1587-1588, rtl_fm.c:812-815;
+                                 127.4 with SDRX_U8_SIGNED_CHAR: Baseband_Stream.cpp:128-148) */
 } sdrx_fir_job;
 
 /* Filter::execute (filt.cpp:267-273) on 1 rail (out0) or on I and Q (out0, out1), optionally

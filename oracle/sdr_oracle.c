@@ -104,6 +104,37 @@ void orc_fir_execute_fma(const double *taps, int T, double *hist, double *buf, s
     free(x);
 }
 
+/* --------------------------------------------------------- u8 I/Q ingest */
+
+/* Baseband_Stream::rotate_90 (Baseband_Stream.cpp:82-101) == rtl_fm.c:282-301: in place, groups of 8 bytes
+ * (4 samples): x1, xj, x(-1), x(-j) with 255 - byte as negation.  len = bytes, a multiple of 8. */
+void orc_u8_rotate_90(uint8_t *buf, size_t len)
+{
+    for (size_t i = 0; i + 8 <= len; i += 8) {
+        uint8_t tmp = (uint8_t)(255 - buf[i + 3]);
+        buf[i + 3] = buf[i + 2];
+        buf[i + 2] = tmp;
+        buf[i + 4] = (uint8_t)(255 - buf[i + 4]);
+        buf[i + 5] = (uint8_t)(255 - buf[i + 5]);
+        tmp = (uint8_t)(255 - buf[i + 6]);
+        buf[i + 6] = buf[i + 7];
+        buf[i + 7] = tmp;
+    }
+}
+
+/* bytes -> I/Q doubles.  signed_char = 0, bias 127: rtlsdr_receiver.cpp:1587-1588 (`buffer[i] - 127` on
+ * unsigned bytes) and rtl_fm.c:812-815.  signed_char = 1, bias 127.4: Baseband_Stream::load_buffer
+ * (Baseband_Stream.cpp:128-148), whose parameter is `char*`: on x86 bytes >= 128 read as negative. */
+void orc_u8_to_iq(const uint8_t *buf, size_t n, double bias, int signed_char, double *re, double *im)
+{
+    for (size_t p = 0; p < n; p++) {
+        double a = signed_char ? (double)(signed char)buf[2 * p] : (double)buf[2 * p];
+        double b = signed_char ? (double)(signed char)buf[2 * p + 1] : (double)buf[2 * p + 1];
+        re[p] = a - bias;
+        im[p] = b - bias;
+    }
+}
+
 /* ---------------------------------------------------------------------- AM */
 
 size_t orc_raw_upsample(const double *in, size_t in_len, double *out, size_t out_len, double ratio)

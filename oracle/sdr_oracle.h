@@ -40,6 +40,9 @@ int orc_fir_design(int type, int two_freq, int num_taps, double Fs, double Fx, d
 void orc_fir_execute(const double *taps, int num_taps, double *sr, double *buf, size_t n);
 /* Same arithmetic (same sums, same order) without the O(T) register shuffle; hist[T-1]
  * holds x[-1], x[-2], ... (newest first) and is updated.  Used for large-N checks. */
+/* u8 I/Q ingest: Baseband_Stream.cpp:82-148, rtlsdr_receiver.cpp:1587-1588, rtl_fm.c:282-301,812-815 */
+void orc_u8_rotate_90(uint8_t *buf, size_t len);
+void orc_u8_to_iq(const uint8_t *buf, size_t n, double bias, int signed_char, double *re, double *im);
 void orc_fir_execute_fast(const double *taps, int num_taps, double *hist, double *buf, size_t n);
 /* fused variant (one rounding per term): the definition of the library's fast_fma modes, not of filt.cpp */
 void orc_fir_execute_fma(const double *taps, int num_taps, double *hist, double *buf, size_t n);

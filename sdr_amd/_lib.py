@@ -6,7 +6,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDRX_LIB_PATH") or os.path.join(HERE, "libsdrx.so")  # override: experiments only
 
-REAL, IQ_SPLIT, IQ_INTERLEAVED = 0, 1, 2
+REAL, IQ_SPLIT, IQ_INTERLEAVED, IQ_U8 = 0, 1, 2, 3
+U8_SIGNED_CHAR, U8_ROTATE90 = 1, 2
 LPF, HPF, BPF = 0, 1, 2
 BPSK, QPSK = 0, 1
 F64, F32 = 0, 1
@@ -26,7 +27,7 @@ class FirJob(C.Structure):
         ("taps", _vp), ("num_taps", C.c_int), ("decim", C.c_uint),
         ("state_in", _vp), ("state_out", _vp), ("state_pitch", _sz),
         ("out0", _vp), ("out1", _vp), ("out_pitch", _sz), ("n_out", _sz),
-        ("stream", _vp), ("dtype", C.c_int),
+        ("stream", _vp), ("dtype", C.c_int), ("u8_flags", C.c_int), ("u8_bias", C.c_double),
     ]
 
 

@@ -44,6 +44,11 @@ class FirChain:
         self.pitch = int(self.L.sdrx_fir_state_doubles(self.T))
         self.state = [torch.zeros(self.nchan, self.pitch, dtype=dtype, device=self.device) for _ in range(2)]
         self.cur = 0
+        self.u8_bias, self.u8_flags = 127.0, 0  # for uint8 {I,Q} inputs: x = byte - 127 (rtlsdr_receiver.cpp:1587-1588)
+
+    def set_u8_conversion(self, bias=127.0, signed_char=False, rotate90=False):
+        self.u8_bias = float(bias)
+        self.u8_flags = (_lib.U8_SIGNED_CHAR if signed_char else 0) | (_lib.U8_ROTATE90 if rotate90 else 0)
 
     def reset(self):
         for s in self.state:
@@ -65,6 +70,7 @@ class FirChain:
         j.out0, j.out1, j.out_pitch, j.n_out = _ptr(out0), _ptr(out1), out_pitch, n_out
         j.stream = _stream()
         j.dtype = _lib.F32 if self.dtype == torch.float32 else _lib.F64
+        j.u8_bias, j.u8_flags = self.u8_bias, self.u8_flags
         return j
 
     def _run(self, fn, name, layout, in0, in1, n, in_pitch, out0, out1, out_pitch, fast_fma=False, n_out=0):
@@ -72,12 +78,16 @@ class FirChain:
         _lib.check(fn(C.byref(j)), name)
         self.cur ^= 1
 
-    # x: (nchan, n, 2) interleaved complex f64, or (re, im) tuple of (nchan, n), or a single real (nchan, n)
+    # x: (nchan, n, 2) interleaved complex, or (re, im) tuple of (nchan, n), or a single real (nchan, n),
+    # or (nchan, n, 2) uint8 = raw RTL-SDR bytes, converted on load
     def _inputs(self, x):
         if isinstance(x, (tuple, list)):
             re, im = x
             assert re.dtype == self.dtype == im.dtype and re.is_contiguous() and im.is_contiguous()
             return _lib.IQ_SPLIT, re, im, re.shape[-1], re.shape[-1]
+        if x.dtype == torch.uint8:  # (nchan, n, 2) raw radio bytes
+            assert x.is_contiguous() and x.dim() == 3 and x.shape[-1] == 2
+            return _lib.IQ_U8, x, None, x.shape[1], x.shape[1]
         assert x.dtype == self.dtype and x.is_contiguous()
         if x.dim() == 3 and x.shape[-1] == 2:
             return _lib.IQ_INTERLEAVED, x, None, x.shape[1], x.shape[1]

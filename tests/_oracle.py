@@ -68,6 +68,10 @@ def lib():
     L.orc_fir_execute.restype = None
     L.orc_fir_execute_fast.argtypes = [_f64, C.c_int, _f64, _f64, _sz]
     L.orc_fir_execute_fast.restype = None
+    L.orc_u8_rotate_90.argtypes = [_u8, _sz]
+    L.orc_u8_rotate_90.restype = None
+    L.orc_u8_to_iq.argtypes = [_u8, _sz, C.c_double, C.c_int, _f64, _f64]
+    L.orc_u8_to_iq.restype = None
     L.orc_fir_execute_fma.argtypes = [_f64, C.c_int, _f64, _f64, _sz]
     L.orc_fir_execute_fma.restype = None
     L.orc_am_modulate.argtypes = [_u8, _sz, _f64, _sz]
@@ -188,6 +192,17 @@ def fm_demodulate(rx_rate, mark, space, re, ds):
     out = np.zeros(re.size // ds + 1, dtype=np.uint8)
     n = lib().orc_fm_demodulate(rx_rate, mark, space, re, out, re.size, ds)
     return out[:n]
+
+
+def u8_to_iq(buf, bias=127.0, signed_char=False, rotate90=False):
+    """raw radio bytes (n, 2) -> (re, im) doubles, optionally after rotate_90 (n a multiple of 4)"""
+    b = np.ascontiguousarray(buf, dtype=np.uint8).reshape(-1).copy()
+    if rotate90:
+        lib().orc_u8_rotate_90(b, b.size)
+    n = b.size // 2
+    re, im = np.zeros(n), np.zeros(n)
+    lib().orc_u8_to_iq(b, n, float(bias), int(bool(signed_char)), re, im)
+    return re, im
 
 
 def fm_discriminator(re, im, pre=None, math_mode=MATH_SHARED):

@@ -361,6 +361,66 @@ def test_fast_modes_are_the_fused_chain_bit_for_bit(mode, T):
                     assert np.array_equal(o1[c].cpu().numpy(), fq.execute_fma(ims[c])), (mode, T, rails, c)
 
 
+# =============================================================================== u8 I/Q ingest
+
+@pytest.mark.parametrize("bias,signed_char,rot", [(127.0, False, False), (127.4, True, False), (127.4, True, True), (127.0, False, True)])
+@pytest.mark.parametrize("D,T", [(10, 64), (1, 64), (4, 129), (100, 64)])
+def test_u8_ingest_chain(D, T, bias, signed_char, rot):
+    """SDRX_IQ_U8: the kernels convert raw radio bytes on load.  Bit-exact against the oracle's
+    restatement of the three reference conversions (rtlsdr_receiver.cpp:1587-1588; Baseband_Stream
+    load_buffer / load_buffer_and_rotate90, Baseband_Stream.cpp:82-148) followed by the fp64 chain;
+    2 channels, two calls with carried state (rotate_90 restarts at every call, like the reference)."""
+    err, taps = O.fir_design(O.LPF, T, 2.4e6, 1.0e5)
+    C_, n = 2, 40000
+    rng = np.random.default_rng(D * 1000 + T)
+    raw = rng.integers(0, 256, (C_, n, 2), dtype=np.uint8)
+    # an FM-ish signal in bytes so that AM bits and angles are not all noise
+    t = np.arange(n)
+    ph = 30 * np.sin(2 * np.pi * t / 2400.0)
+    raw[0, :, 0] = np.clip(np.round(127.4 + 100 * np.cos(ph)), 0, 255).astype(np.uint8)
+    raw[0, :, 1] = np.clip(np.round(127.4 + 100 * np.sin(ph)), 0, 255).astype(np.uint8)
+    x = torch.tensor(raw, device="cuda")
+    n_out = (n + D - 1) // D
+    cd = device.FirChain(taps, nchan=C_, decim=D)
+    ca = device.FirChain(taps, nchan=C_, decim=D)
+    for ch in (cd, ca):
+        ch.set_u8_conversion(bias, signed_char, rot)
+    got = []
+    for _ in range(2):
+        ang = torch.zeros(C_, n_out, dtype=torch.float64, device="cuda")
+        bits = torch.zeros(C_, n_out, dtype=torch.uint8, device="cuda")
+        cd.fir_fmdisc(x, ang)
+        ca.fir_am(x, bits)
+        got.append((ang.cpu().numpy(), bits.cpu().numpy()))
+    for c in range(C_):
+        re, im = O.u8_to_iq(raw[c], bias, signed_char, rot)
+        H = max(T - 1, 1)
+        hI, hQ, pre = np.zeros(H), np.zeros(H), np.zeros(2)
+        aI, aQ = np.zeros(H), np.zeros(H)
+        for ang, bits in got:
+            assert np.array_equal(ang[c], _oracle_chain_disc(taps, re, im, D, hI, hQ, pre)), (c,)
+            assert np.array_equal(bits[c], _oracle_chain_am(taps, re, im, D, aI, aQ)), (c,)
+
+
+def test_u8_ingest_f32():
+    """u8 bytes straight into the fp32 twin: within 1e-5 of the fp64 path on the same bytes."""
+    err, taps = O.fir_design(O.LPF, 64, 2.4e6, 1.0e5)
+    n, D = 50000, 10
+    raw = np.random.default_rng(3).integers(0, 256, (1, n, 2), dtype=np.uint8)
+    x = torch.tensor(raw, device="cuda")
+    ch = device.FirChain(taps, nchan=1, decim=D, dtype=torch.float32)
+    o0 = torch.zeros(1, n // D, dtype=torch.float32, device="cuda")
+    o1 = torch.zeros(1, n // D, dtype=torch.float32, device="cuda")
+    ch.fir(x, o0, o1)
+    re, im = O.u8_to_iq(raw[0])
+    yi = O.Fir(O.LPF, 64, 2.4e6, 1.0e5).execute(re, fast=True)[::D]
+    yq = O.Fir(O.LPF, 64, 2.4e6, 1.0e5).execute(im, fast=True)[::D]
+    si = (np.convolve(np.abs(re), np.abs(taps))[:n] + 1e-30)[::D]
+    sq = (np.convolve(np.abs(im), np.abs(taps))[:n] + 1e-30)[::D]
+    assert np.max(np.abs(o0[0].cpu().numpy() - yi) / si) <= 1e-5
+    assert np.max(np.abs(o1[0].cpu().numpy() - yq) / sq) <= 1e-5
+
+
 # =============================================================================== fp32 twins
 
 @pytest.mark.parametrize("D,T", [(1, 64), (4, 129), (10, 64), (8, 64), (5, 33), (12, 100), (3, 64), (100, 64)])
