@@ -327,3 +327,35 @@ def test_chain_streaming_equals_one_shot():
         mm = L.orc_chain_fir_decim_disc(taps, 64, hI2, hQ2, pre2, r, i, r.size, 10, o, O.MATH_SHARED)
         parts.append(o[:mm])
     assert np.array_equal(np.concatenate(parts)[:m], out[:m])
+
+
+# ---------------------------------------------------------------- oracle helpers without a reference KAT
+
+def test_u8_ingest_restatement():
+    """orc_u8_to_iq / orc_u8_rotate_90 follow rtlsdr_receiver.cpp:1587-1588 and Baseband_Stream.cpp:82-148.
+    The reference holds no vector for them (parity unpinned): check the defining properties instead --
+    byte - 127 on unsigned bytes, char semantics for load_buffer, and rotate_90 = multiplication of the
+    sample sequence by 1, j, -1, -j when a byte's negation is 255 - byte."""
+    raw = np.arange(512, dtype=np.uint8).reshape(-1, 2)  # every byte value (wraps)
+    re, im = O.u8_to_iq(raw)
+    assert np.array_equal(re, raw[:, 0].astype(np.float64) - 127.0)
+    assert np.array_equal(im, raw[:, 1].astype(np.float64) - 127.0)
+    re, im = O.u8_to_iq(raw, 127.4, signed_char=True)
+    assert np.array_equal(re, raw[:, 0].astype(np.int8).astype(np.float64) - 127.4)
+    rng = np.random.default_rng(0)
+    raw = rng.integers(0, 256, (64, 2), dtype=np.uint8)
+    r0, i0 = O.u8_to_iq(raw, 127.5)
+    r1, i1 = O.u8_to_iq(raw, 127.5, rotate90=True)  # with bias 127.5, 255 - b maps to exactly -(b - 127.5)
+    z0, z1 = r0 + 1j * i0, r1 + 1j * i1
+    assert np.array_equal(z1, z0 * np.tile([1, 1j, -1, -1j], 16))
+
+
+def test_fused_fir_variant_is_close_to_the_reference_sum():
+    """orc_fir_execute_fma defines the library's fast modes; it must stay within 1e-12 * sum|h||x| of Filter::execute."""
+    rng = np.random.default_rng(1)
+    x = rng.integers(-127, 128, 5000).astype(np.float64)
+    for T in (1, 2, 64, 129, 1000):
+        a, b = O.Fir(O.LPF, T, 2.0e6, 1.0e5), O.Fir(O.LPF, T, 2.0e6, 1.0e5)
+        scale = np.convolve(np.abs(x), np.abs(a.taps))[: x.size] + 1e-300
+        for lo, hi in ((0, 1234), (1234, 5000)):
+            assert np.max(np.abs(a.execute(x[lo:hi]) - b.execute_fma(x[lo:hi])) / scale[lo:hi]) <= 1e-12
