@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="f32: the fp32 twins (cfg1, cfg2, cfg4)")
     ap.add_argument("--ingest", default="fp", choices=["fp", "u8"],
                     help="u8: the input is the radio's raw uint8 {I,Q} stream, converted on load (cfg1, cfg2, cfg4)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / max-over-ranks (gloo + SDRX_BENCH_SHARE_GPU=1: "
+                         "rehearse the multi-rank path on a one-GPU box, every rank on cuda:0)")
     ap.add_argument("--fast-fma", action="store_true")
     ap.add_argument("--mfma", action="store_true", help="cfg5: fp64 MFMA Toeplitz formulation (fast mode 2)")
     args = ap.parse_args()
@@ -99,8 +102,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("SDRX_BENCH_SHARE_GPU"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     device.init(local_rank)
@@ -205,7 +213,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    dt = shard.max_over_ranks(dt, device=dev)
+    dt = shard.max_over_ranks(dt, device=dev if args.backend == "nccl" else "cpu")
 
     if rank == 0:
         launch_s = ev_ms / 1e3 / args.steps  # HIP events on the launch stream, averaged over the timed steps
