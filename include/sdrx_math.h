@@ -68,28 +68,28 @@ SDRX_HD void sdrx_sincos(double x, double *s, double *c)
                  P3 = 2.02226624871116645580e-21, P3T = 8.47842766036889956997e-32;
     /* 2^20 * 2*pi split in three pieces with 26 trailing zero bits each (coarse stage for huge |x|) */
     const double M1 = 6588397.0, M2 = 0.31666114181280136 /* 0x1.4442d18p-2 */, M3 = 2.56827048412547e-10;
-    double ax = x < 0.0 ? -x : x;
-    if (!(ax < 1.0e300)) { /* inf / nan / absurd */
-        *s = x - x;
-        *c = x - x;
-        return;
-    }
-    if (ax > 1.5e6) {
-        double q = rint(x * 1.5178198155583891e-07); /* 1/(2^20*2pi) */
-        x = ((x - q * M1) - q * M2) - q * M3;
-    }
-    double fn = rint(x * INV_PIO2);
+    /* Straight-line on purpose (selects, no branches): inside the PSK carrier loop this runs next to
+     * the independent timing-loop arithmetic of the following sample, and one basic block lets the
+     * compiler interleave the two dependency chains.  Values are those of the branching form. */
+    const double x0 = x;
+    const double ax = x < 0.0 ? -x : x;
+    const int bad = !(ax < 1.0e300); /* inf / nan / absurd */
+    const int big = ax > 1.5e6;
+    const double q = rint(x * 1.5178198155583891e-07); /* 1/(2^20*2pi) */
+    const double xr = ((x - q * M1) - q * M2) - q * M3;
+    x = big ? xr : x;
+    const double fn = rint(x * INV_PIO2);
     double r = ((x - fn * P1) - fn * P2) - fn * P3;
     r = r - fn * P3T;
-    long long n = (long long)fn;
-    double sr = sdrx_ksin(r);
-    double cr = sdrx_kcos(r);
-    switch ((int)(n & 3)) {
-    case 0: *s = sr; *c = cr; break;
-    case 1: *s = cr; *c = -sr; break;
-    case 2: *s = -sr; *c = -cr; break;
-    default: *s = -cr; *c = sr; break;
-    }
+    const int k = bad ? 0 : ((int)fn & 3); /* |fn| < 2^23 whenever the result is used */
+    const double sr = sdrx_ksin(r);
+    const double cr = sdrx_kcos(r);
+    const double ss = (k & 1) ? cr : sr; /* k = 0: s =  sr, c =  cr */
+    const double cc = (k & 1) ? sr : cr; /* k = 1: s =  cr, c = -sr */
+    const double sv = (k & 2) ? -ss : ss; /* k = 2: s = -sr, c = -cr */
+    const double cv = ((k + 1) & 2) ? -cc : cc; /* k = 3: s = -cr, c =  sr */
+    *s = bad ? x0 - x0 : sv;
+    *c = bad ? x0 - x0 : cv;
 }
 
 /* ---- atan / atan2 ------------------------------------------------------- */

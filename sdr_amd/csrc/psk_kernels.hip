@@ -79,110 +79,145 @@ __device__ __forceinline__ double interp_filter(Interp &d, double in, double mu)
     return V8;
 }
 
-__global__ void __launch_bounds__(64) psk_loops_kernel(int kind, double2 *__restrict__ mf, size_t m, size_t nchan,
-                                                       size_t pitch, sdrx_psk_state *__restrict__ states,
-                                                       uint8_t *__restrict__ dec, size_t out_pitch, int run_timing,
-                                                       int run_phase)
+// Loop state of one channel, in registers.
+struct TimingState {
+    double nco, reg_mu, reg_Q, reg_I, mu_delay;
+    Interp iq, ii;
+    double g1, g2, g3, g4, lf_x, lf_y;
+};
+struct PhaseState {
+    double dds_delay, plf_x, plf_y;
+    double tr, ti, temp; // locals of phase_shift_correction: restart at 0 every call
+};
+
+// One sample through symbol_timing_synchronization (BPSK.cpp:307-316): (re, im) -> (reg_Q, reg_I).
+__device__ __forceinline__ void timing_step(TimingState &t, double &re, double &im)
+{
+    const double strobe = (t.nco < 0) ? 1.0 : 0.0;
+    t.reg_mu = (strobe >= 1) ? t.mu_delay * 2 : t.reg_mu;
+    const double mu = t.reg_mu;
+    const double Q = interp_filter(t.iq, re, mu); // "Q" is fed the real rail (BPSK.cpp:311)
+    const double I = interp_filter(t.ii, im, mu);
+    // GardnerDetector, BPSK.cpp:346-363
+    const double eg = (t.g3 * (-SDRX_SGN(Q) + SDRX_SGN(t.g4)) + (t.g1 * (-SDRX_SGN(I) + SDRX_SGN(t.g2))));
+    const double e = (strobe >= 0.5) ? eg : 0.0;
+    t.g2 = t.g1;
+    t.g1 = I;
+    t.g4 = t.g3;
+    t.g3 = Q;
+    const double K1 = -0.00587880145347487, K2 = -2.35152058138995e-05; // LoopFilter, BPSK.cpp:365-373
+    const double v = t.lf_y + K2 * e + K1 * (e - t.lf_x);
+    t.lf_x = e;
+    t.lf_y = v;
+    const double eta = t.nco - floor(t.nco); // NcoControl, BPSK.cpp:375-380
+    t.nco = eta - 0.5 - v;
+    t.mu_delay = eta;
+    t.reg_Q = (strobe >= 1) ? Q : t.reg_Q;
+    t.reg_I = (strobe >= 1) ? I : t.reg_I;
+    re = t.reg_Q;
+    im = t.reg_I;
+}
+
+// One sample through phase_shift_correction + the output lookup; returns the decision.
+template <int KIND> __device__ __forceinline__ int phase_step(PhaseState &p, double re, double im)
+{
+    const double PK1 = 0.0620001240002480, PK2 = 0.000992001984003968; // BPSK.cpp:424-432
+    double sn, cs;
+    if constexpr (KIND == SDRX_BPSK) { // BPSK.cpp:399-411
+        sdrx_sincos(p.dds_delay + p.temp, &sn, &cs);
+        p.dds_delay = p.dds_delay + p.temp;
+        p.tr = re * cs - im * sn;
+        p.ti = im * cs + re * sn;
+        const double val = 8.0 * (SDRX_SGN(p.ti) * p.tr - SDRX_SGN(p.tr) * p.ti);
+        p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
+        p.plf_x = val;
+        p.plf_y = p.temp;
+        return (SDRX_SGN(p.tr) < 0) ? 1 : 0;
+    } else { // QPSK.cpp:361-373: loop filter first, from the previous product
+        const double val = 8.0 * (SDRX_SGN(p.ti) * p.tr - SDRX_SGN(p.tr) * p.ti);
+        p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
+        p.plf_x = val;
+        p.plf_y = p.temp;
+        sdrx_sincos(p.dds_delay + p.temp, &sn, &cs);
+        p.dds_delay = p.dds_delay + p.temp;
+        p.tr = re * cs - im * sn;
+        p.ti = im * cs + re * sn;
+        const double sr = SDRX_SGN(p.tr), si = SDRX_SGN(p.ti); // QPSK.cpp:396-414
+        return (sr < 0 && si < 0) ? 3 : ((sr > 0 && si < 0) ? 2 : ((sr < 0 && si > 0) ? 1 : 0));
+    }
+}
+
+// The two loops are each one long dependency chain per sample, but the timing loop of sample i+1
+// does not depend on the carrier loop of sample i: the kernel runs them one sample apart in the
+// same straight-line block (no branches inside: every conditional above is a select), so the
+// compiler interleaves the two chains and a lone wave keeps the VALU busy during each other's latencies.
+template <int KIND, bool TIMING, bool PHASE>
+__global__ void __launch_bounds__(64) psk_loops_kernel(double2 *__restrict__ mf, size_t m, size_t nchan, size_t pitch,
+                                                       sdrx_psk_state *__restrict__ states, uint8_t *__restrict__ dec,
+                                                       size_t out_pitch)
 {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchan) return;
     sdrx_psk_state *st = states + c;
-    double nco = st->nco_delay, reg_mu = st->reg_mu, reg_Q = st->reg_Q, reg_I = st->reg_I, mu_delay = st->mu_delay;
-    Interp iq = {st->iq_d[0], st->iq_d[1], st->iq_d[2], st->iq_d[3], st->iq_d[4]};
-    Interp ii = {st->ii_d[0], st->ii_d[1], st->ii_d[2], st->ii_d[3], st->ii_d[4]};
-    double g1 = st->g1, g2 = st->g2, g3 = st->g3, g4 = st->g4;
-    double lf_x = st->lf_x, lf_y = st->lf_y;
-    double dds_delay = st->dds_delay, plf_x = st->plf_x, plf_y = st->plf_y;
-    double tr = 0.0, ti = 0.0, temp = 0.0; // locals of phase_shift_correction: restart at 0 every call
-
+    TimingState t = {st->nco_delay, st->reg_mu, st->reg_Q, st->reg_I, st->mu_delay,
+                     {st->iq_d[0], st->iq_d[1], st->iq_d[2], st->iq_d[3], st->iq_d[4]},
+                     {st->ii_d[0], st->ii_d[1], st->ii_d[2], st->ii_d[3], st->ii_d[4]},
+                     st->g1, st->g2, st->g3, st->g4, st->lf_x, st->lf_y};
+    PhaseState p = {st->dds_delay, st->plf_x, st->plf_y, 0.0, 0.0, 0.0};
     double2 *x = mf + c * pitch;
-    uint8_t *d = dec ? dec + c * out_pitch : nullptr;
+    uint8_t *d = dec + c * out_pitch;
+
+    // what the carrier loop (or the store, in a timing-only run) does with the timing loop's sample i
+    auto finish = [&](double re, double im, size_t i, bool even) {
+        if constexpr (PHASE) {
+            const int decision = phase_step<KIND>(p, re, im);
+            if (even) d[i >> 1] = (uint8_t)decision; // decimate(real, n, 2): keeps 0, 2, 4, ...
+        } else {
+            x[i] = make_double2(re, im);
+        }
+    };
 
     constexpr int PF = 4; // samples fetched ahead per lane: one 64-byte line
-    double2 nxt[PF];
+    const size_t full = m - m % PF;
+    double pr = 0.0, pi = 0.0; // sample i-1 after the timing loop, waiting for its carrier-loop turn
+    if (full) {
+        double2 nxt[PF];
 #pragma unroll
-    for (int k = 0; k < PF; k++) nxt[k] = ((size_t)k < m) ? x[k] : make_double2(0.0, 0.0);
-
-    for (size_t i0 = 0; i0 < m; i0 += PF) {
-        double2 cur[PF];
+        for (int k = 0; k < PF; k++) nxt[k] = x[k];
+        for (size_t i0 = 0; i0 < full; i0 += PF) {
+            double2 cur[PF];
 #pragma unroll
-        for (int k = 0; k < PF; k++) cur[k] = nxt[k];
+            for (int k = 0; k < PF; k++) cur[k] = nxt[k];
+            if (i0 + PF < full) {
 #pragma unroll
-        for (int k = 0; k < PF; k++) {
-            size_t ii2 = i0 + PF + k;
-            nxt[k] = (ii2 < m) ? x[ii2] : make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const size_t i = i0 + k;
-            if (i >= m) break;
-            double re = cur[k].x, im = cur[k].y;
-            if (run_timing) { // BPSK.cpp:307-316
-                const double strobe = (nco < 0) ? 1.0 : 0.0;
-                if (strobe >= 1) reg_mu = mu_delay * 2;
-                const double mu = reg_mu;
-                const double Q = interp_filter(iq, re, mu); // "Q" is fed the real rail (BPSK.cpp:311)
-                const double I = interp_filter(ii, im, mu);
-                double e = 0; // GardnerDetector, BPSK.cpp:346-363
-                if (strobe >= 0.5) e = (g3 * (-SDRX_SGN(Q) + SDRX_SGN(g4)) + (g1 * (-SDRX_SGN(I) + SDRX_SGN(g2))));
-                g2 = g1;
-                g1 = I;
-                g4 = g3;
-                g3 = Q;
-                const double K1 = -0.00587880145347487, K2 = -2.35152058138995e-05; // LoopFilter, BPSK.cpp:365-373
-                const double v = lf_y + K2 * e + K1 * (e - lf_x);
-                lf_x = e;
-                lf_y = v;
-                const double eta = nco - floor(nco); // NcoControl, BPSK.cpp:375-380
-                nco = eta - 0.5 - v;
-                mu_delay = eta;
-                if (strobe >= 1) { reg_Q = Q; reg_I = I; }
-                re = reg_Q;
-                im = reg_I;
-                if (!run_phase) x[i] = make_double2(re, im);
+                for (int k = 0; k < PF; k++) nxt[k] = x[i0 + PF + k];
             }
-            if (run_phase) {
-                const double PK1 = 0.0620001240002480, PK2 = 0.000992001984003968; // BPSK.cpp:424-432
-                double sn, cs;
-                int decision;
-                if (kind == SDRX_BPSK) { // BPSK.cpp:399-411
-                    sdrx_sincos(dds_delay + temp, &sn, &cs);
-                    dds_delay = dds_delay + temp;
-                    tr = re * cs - im * sn;
-                    ti = im * cs + re * sn;
-                    const double val = 8.0 * (SDRX_SGN(ti) * tr - SDRX_SGN(tr) * ti);
-                    temp = plf_y - PK1 * plf_x + (PK1 + PK2) * val;
-                    plf_x = val;
-                    plf_y = temp;
-                    decision = (SDRX_SGN(tr) < 0) ? 1 : 0;
-                } else { // QPSK.cpp:361-373: loop filter first, from the previous product
-                    const double val = 8.0 * (SDRX_SGN(ti) * tr - SDRX_SGN(tr) * ti);
-                    temp = plf_y - PK1 * plf_x + (PK1 + PK2) * val;
-                    plf_x = val;
-                    plf_y = temp;
-                    sdrx_sincos(dds_delay + temp, &sn, &cs);
-                    dds_delay = dds_delay + temp;
-                    tr = re * cs - im * sn;
-                    ti = im * cs + re * sn;
-                    const double sr = SDRX_SGN(tr), si = SDRX_SGN(ti); // QPSK.cpp:396-414
-                    if (sr < 0 && si < 0) decision = 3;
-                    else if (sr > 0 && si < 0) decision = 2;
-                    else if (sr < 0 && si > 0) decision = 1;
-                    else decision = 0;
-                }
-                if ((i & 1) == 0 && d) d[i >> 1] = (uint8_t)decision; // decimate(real, n, 2): keeps 0,2,4,...
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                double re = cur[k].x, im = cur[k].y;
+                // sample i0+k-1 through the carrier loop, sample i0+k through the timing loop: independent
+                if (k > 0 || i0 > 0) finish(pr, pi, i0 + k - 1, ((k - 1) & 1) == 0);
+                if constexpr (TIMING) timing_step(t, re, im);
+                pr = re;
+                pi = im;
             }
         }
+        finish(pr, pi, full - 1, ((PF - 1) & 1) == 0);
     }
-    if (run_timing) {
-        st->nco_delay = nco; st->reg_mu = reg_mu; st->reg_Q = reg_Q; st->reg_I = reg_I; st->mu_delay = mu_delay;
-        st->iq_d[0] = iq.d1; st->iq_d[1] = iq.d2; st->iq_d[2] = iq.d3; st->iq_d[3] = iq.d4; st->iq_d[4] = iq.d5;
-        st->ii_d[0] = ii.d1; st->ii_d[1] = ii.d2; st->ii_d[2] = ii.d3; st->ii_d[3] = ii.d4; st->ii_d[4] = ii.d5;
-        st->g1 = g1; st->g2 = g2; st->g3 = g3; st->g4 = g4;
-        st->lf_x = lf_x; st->lf_y = lf_y;
+    for (size_t i = full; i < m; i++) { // ragged tail, one sample at a time
+        double re = x[i].x, im = x[i].y;
+        if constexpr (TIMING) timing_step(t, re, im);
+        finish(re, im, i, (i & 1) == 0);
     }
-    if (run_phase) {
-        st->dds_delay = dds_delay; st->plf_x = plf_x; st->plf_y = plf_y;
+    if constexpr (TIMING) {
+        st->nco_delay = t.nco; st->reg_mu = t.reg_mu; st->reg_Q = t.reg_Q; st->reg_I = t.reg_I; st->mu_delay = t.mu_delay;
+        st->iq_d[0] = t.iq.d1; st->iq_d[1] = t.iq.d2; st->iq_d[2] = t.iq.d3; st->iq_d[3] = t.iq.d4; st->iq_d[4] = t.iq.d5;
+        st->ii_d[0] = t.ii.d1; st->ii_d[1] = t.ii.d2; st->ii_d[2] = t.ii.d3; st->ii_d[3] = t.ii.d4; st->ii_d[4] = t.ii.d5;
+        st->g1 = t.g1; st->g2 = t.g2; st->g3 = t.g3; st->g4 = t.g4;
+        st->lf_x = t.lf_x; st->lf_y = t.lf_y;
+    }
+    if constexpr (PHASE) {
+        st->dds_delay = p.dds_delay; st->plf_x = p.plf_x; st->plf_y = p.plf_y;
     }
 }
 
@@ -193,11 +228,19 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
         set_error("psk_loops: bad argument");
         return SDRX_EINVAL;
     }
-    if (nchan == 0 || m == 0) return SDRX_OK;
+    if (nchan == 0 || m == 0 || (!run_timing && !run_phase)) return SDRX_OK;
     size_t blocks = (nchan + 63) / 64;
     if (blocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
-    hipLaunchKernelGGL(psk_loops_kernel, dim3((unsigned)blocks), dim3(64), 0, s, kind, (double2 *)mf_iq, m, nchan,
-                       mf_pitch, states, decisions, out_pitch, run_timing, run_phase);
+    typedef void (*fn_t)(double2 *, size_t, size_t, size_t, sdrx_psk_state *, uint8_t *, size_t);
+    fn_t fn;
+    if (kind == SDRX_BPSK)
+        fn = run_timing ? (run_phase ? psk_loops_kernel<SDRX_BPSK, true, true> : psk_loops_kernel<SDRX_BPSK, true, false>)
+                        : psk_loops_kernel<SDRX_BPSK, false, true>;
+    else
+        fn = run_timing ? (run_phase ? psk_loops_kernel<SDRX_QPSK, true, true> : psk_loops_kernel<SDRX_QPSK, true, false>)
+                        : psk_loops_kernel<SDRX_QPSK, false, true>;
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64), 0, s, (double2 *)mf_iq, m, nchan, mf_pitch, states, decisions,
+                       out_pitch);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }
