@@ -250,10 +250,14 @@ extern "C" int sdrx_psk_matched_filter_dev(const double *iq, size_t n, size_t nc
                                            size_t mf_pitch, void *stream)
 {
     if (!iq || !mf_iq) return SDRX_EINVAL;
-    std::lock_guard<std::mutex> lk(g_mu);
+    // (psk_mf_taps_dev takes g_mu itself: this entry point used to hold it across the call and deadlocked)
+    static std::mutex scratch_mu;
     const size_t st_bytes = align256(nchan * MF_STATE * sizeof(double));
-    int rc = g_mf_scratch.ensure(2 * st_bytes);
-    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(scratch_mu);
+        int rc = g_mf_scratch.ensure(2 * st_bytes);
+        if (rc) return rc;
+    }
     return mf_launch(iq, n, nchan, in_pitch, mf_iq, mf_pitch, (double *)g_mf_scratch.p,
                      (double *)((unsigned char *)g_mf_scratch.p + st_bytes), (hipStream_t)stream);
 }

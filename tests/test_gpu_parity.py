@@ -639,6 +639,35 @@ def test_psk_bank_multichannel_device():
                 assert np.array_equal(mine, sts[c].loop_state())
 
 
+def test_psk_stage_entry_points_equal_the_fused_call():
+    """sdrx_psk_matched_filter_dev -> sdrx_psk_loops_dev (timing, then carrier, as separate launches and as
+    one) -> sdrx_psk_ambiguity_dev give the decisions and loop state of sdrx_psk_demod_dev, bit for bit."""
+    Lx = _lib.lib()
+    nchan, n = 70, 4096
+    iqs = [psk_test_signal(O.QPSK, n // 8, seed=200 + c, phase_deg=90.0 * (c % 4), snr_db=20.0, timing_offset=c % 3)
+           for c in range(nchan)]
+    iq = np.stack([np.asarray(z).reshape(-1, 2) for z in iqs])
+    x = torch.tensor(np.ascontiguousarray(iq), device="cuda")
+    ref = device.PskBank(_lib.QPSK, nchan, n)
+    want = torch.zeros(nchan, ref.n_dec, dtype=torch.uint8, device="cuda")
+    ref.demod(x, want)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for split in (False, True):
+        b = device.PskBank(_lib.QPSK, nchan, n)
+        mf = torch.zeros(nchan, n // 4, 2, dtype=torch.float64, device="cuda")
+        got = torch.zeros(nchan, ref.n_dec, dtype=torch.uint8, device="cuda")
+        _lib.check(Lx.sdrx_psk_matched_filter_dev(vp(x), n, nchan, n, vp(mf), n // 4, None))
+        if split:
+            _lib.check(Lx.sdrx_psk_loops_dev(_lib.QPSK, vp(mf), n // 4, nchan, n // 4, vp(b.states), vp(got), got.shape[1], 1, 0, None))
+            _lib.check(Lx.sdrx_psk_loops_dev(_lib.QPSK, vp(mf), n // 4, nchan, n // 4, vp(b.states), vp(got), got.shape[1], 0, 1, None))
+        else:
+            _lib.check(Lx.sdrx_psk_loops_dev(_lib.QPSK, vp(mf), n // 4, nchan, n // 4, vp(b.states), vp(got), got.shape[1], 1, 1, None))
+        _lib.check(Lx.sdrx_psk_ambiguity_dev(_lib.QPSK, vp(got), (n // 4 + 1) // 2, nchan, got.shape[1], vp(b.states), None))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), split
+        assert torch.equal(b.states, ref.states), split
+
+
 def test_psk_modulators_vs_oracle():
     """BPSK/QPSK::modulate incl. the byte-count memset (prior contents beyond len_mod/8 accumulate)."""
     rng = np.random.default_rng(5)
