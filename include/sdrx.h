@@ -120,6 +120,15 @@ int sdrx_ones_zeros_dev(const double *re, const double *im, size_t n, int32_t *c
 int sdrx_fm_demod_dev(const double *re, const double *w1, const double *w2, uint8_t *out, size_t n, size_t ds,
                       void *stream);
 
+/* rtl_fm's own int16 chain on raw radio bytes, fused (third-party/RTLSDR/rtl_fm.c): rtlsdr_callback's
+ * conversion (:808-822: optional rotate_90, (int16)byte - 127), low_pass (:303-323: boxcar sum of
+ * `downsample` samples, narrowed to int16) and fm_demod with polar_discriminant (:422-435, :518-546):
+ * pcm = (int)(atan2(Im, Re of z[m] conj z[m-1]) / 3.14159 * 2^14).  State per channel, 5 x int32:
+ * now_r, now_j, prev_index (the partial boxcar sum), pre_r, pre_j; state_in != state_out.  Writes
+ * (prev_index + n) / downsample pcm samples per channel (the caller tracks prev_index = (prev_index + n) % downsample). */
+int sdrx_rtlfm_dev(const uint8_t *iq_u8, size_t n, size_t nchan, size_t in_pitch, int downsample, int rotate90,
+                   const int32_t *state_in, int32_t *state_out, int16_t *pcm, size_t out_pitch, void *stream);
+
 /* PSK loop state of one channel: the reference's public loop structs (BPSK.h:130-276) flattened. */
 typedef struct sdrx_psk_state {
     double nco_delay, reg_mu, reg_Q, reg_I, mu_delay; /* NcoControlVariables.delay, Register_*, muDelay */

@@ -256,6 +256,50 @@ void orc_fm_discriminator_i16(const int16_t *iq, size_t n, int16_t *pre, int16_t
     pre[1] = (int16_t)pj;
 }
 
+/* rtl_fm's own chain around the discriminator, restated on its int16 data path:
+ * rtlsdr_callback (rtl_fm.c:808-822): optional rotate_90, buf16 = (int16)byte - 127;
+ * low_pass (rtl_fm.c:303-323): boxcar sum of `downsample` samples, partial sum carried in now_r/now_j/prev_index,
+ * stored back as int16; fm_demod (rtl_fm.c:518-546) with custom_atan == 0.  st = {now_r, now_j, prev_index, pre_r, pre_j}.
+ * Returns the number of pcm samples written.  (rtl_fm.c needs librtlsdr and is not built here: parity unpinned.) */
+size_t orc_rtlfm_chain(const uint8_t *iq_u8, size_t n, int downsample, int rotate90, int32_t *st, int16_t *pcm,
+                       int math_mode)
+{
+    size_t len = 2 * n;
+    uint8_t *buf = (uint8_t *)malloc(len ? len : 1);
+    int16_t *lp = (int16_t *)malloc((len ? len : 1) * sizeof(int16_t));
+    memcpy(buf, iq_u8, len);
+    if (rotate90) orc_u8_rotate_90(buf, len);
+    for (size_t i = 0; i < len; i++) lp[i] = (int16_t)((int16_t)buf[i] - 127);
+    int now_r = st[0], now_j = st[1], prev_index = st[2];
+    size_t i = 0, i2 = 0;
+    while (i < len) { /* low_pass */
+        now_r += lp[i];
+        now_j += lp[i + 1];
+        i += 2;
+        prev_index++;
+        if (prev_index < downsample) continue;
+        lp[i2] = (int16_t)now_r;
+        lp[i2 + 1] = (int16_t)now_j;
+        prev_index = 0;
+        now_r = 0;
+        now_j = 0;
+        i2 += 2;
+    }
+    st[0] = now_r;
+    st[1] = now_j;
+    st[2] = prev_index;
+    size_t m = i2 / 2;
+    if (m) { /* fm_demod: with lp_len == 0 the reference would read lp[-2]; it is never called that way */
+        int16_t pre[2] = {(int16_t)st[3], (int16_t)st[4]};
+        orc_fm_discriminator_i16(lp, m, pre, pcm, math_mode);
+        st[3] = pre[0];
+        st[4] = pre[1];
+    }
+    free(buf);
+    free(lp);
+    return m;
+}
+
 /* ---------------------------------------------------------------- Resample */
 
 size_t orc_decimate(double *block, size_t length, size_t by)

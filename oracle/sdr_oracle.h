@@ -66,6 +66,9 @@ void orc_fm_discriminator(const double *re, const double *im, size_t n, double *
                           int math_mode);
 /* rtl_fm.c:428-435 on int16 I/Q pairs: (int)(angle / 3.14159 * (1<<14)) */
 void orc_fm_discriminator_i16(const int16_t *iq, size_t n, int16_t *pre, int16_t *out, int math_mode);
+/* rtl_fm.c:808-822 (u8 -> int16), :303-323 (boxcar low_pass), :518-546 (fm_demod); st = now_r, now_j, prev_index, pre_r, pre_j */
+size_t orc_rtlfm_chain(const uint8_t *iq_u8, size_t n, int downsample, int rotate90, int32_t *st, int16_t *pcm,
+                       int math_mode);
 
 /* ---- Resample.{h,cpp} ---- */
 size_t orc_decimate(double *block, size_t length, size_t by);                                  /* Resample.h:33-52 */

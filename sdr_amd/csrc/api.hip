@@ -131,6 +131,13 @@ extern "C" int sdrx_fir_dev(const sdrx_fir_job *job) { return launch_fir(job, EP
 extern "C" int sdrx_fir_am_dev(const sdrx_fir_job *job) { return launch_fir(job, EPI_AM); }
 extern "C" int sdrx_fir_fmdisc_dev(const sdrx_fir_job *job) { return launch_fir(job, EPI_DISC); }
 
+extern "C" int sdrx_rtlfm_dev(const uint8_t *iq_u8, size_t n, size_t nchan, size_t in_pitch, int downsample, int rotate90,
+                              const int32_t *state_in, int32_t *state_out, int16_t *pcm, size_t out_pitch, void *stream)
+{
+    return launch_rtlfm(iq_u8, n, nchan, in_pitch, downsample, rotate90, state_in, state_out, pcm, out_pitch,
+                        (hipStream_t)stream);
+}
+
 extern "C" int sdrx_am_demod_dev(const double *re, const double *im, uint8_t *out, size_t n, size_t ds, void *stream)
 {
     return launch_am_demod(re, im, out, n, ds, (hipStream_t)stream);

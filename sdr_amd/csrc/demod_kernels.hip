@@ -6,6 +6,8 @@
 //   fsk_corr_kernel    : FM<T>::demodulate (FM.h:83-148 with the SURVEY section 8c repair)
 #include "sdrx_internal.h"
 
+#include "../../include/sdrx_math.h"
+
 namespace sdrx {
 
 // ---------------------------------------------------------------------------------------- AM
@@ -164,6 +166,92 @@ int launch_fm_demod(const double *re, const double *w1, const double *w2, uint8_
     if (blocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
     hipLaunchKernelGGL(fsk_corr_kernel, dim3((unsigned)blocks), dim3(FSK_NT), 0, s, re, w1, w2, out, nbits,
                        (unsigned)ds);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+// ------------------------------------------------------------------------ rtl_fm int16 chain
+//
+// rtlsdr_callback's conversion (rtl_fm.c:808-822), low_pass (rtl_fm.c:303-323) and fm_demod with
+// polar_discriminant (rtl_fm.c:422-435, 518-546), fused: one thread per decimated sample.  A thread
+// sums its `ds` raw byte pairs (the first one of a call continues the carried partial sum), the
+// sums are narrowed to int16 like `lowpassed[]`, the previous decimated sample comes from the
+// neighbouring lane (across waves through LDS, across workgroups by recomputing one sum), and
+// pcm = (int)(atan2(cj, cr) / 3.14159 * 2^14).  All integer steps are exact; atan2 is include/sdrx_math.h.
+__device__ __forceinline__ void rtlfm_sum(const uint8_t *__restrict__ x, long long first, long long last, int rotate90,
+                                          int &sr, int &sj)
+{
+    for (long long i = first; i < last; i++) { // sample index within the call
+        unsigned a = x[2 * i], b = x[2 * i + 1];
+        if (rotate90) {
+            const unsigned ph = (unsigned)i & 3u, a0 = a, b0 = b;
+            a = ph == 0 ? a0 : (ph == 1 ? 255u - b0 : (ph == 2 ? 255u - a0 : b0));
+            b = ph == 0 ? b0 : (ph == 1 ? a0 : (ph == 2 ? 255u - b0 : 255u - a0));
+        }
+        sr += (int)a - 127;
+        sj += (int)b - 127;
+    }
+}
+
+__global__ void __launch_bounds__(256) rtlfm_kernel(const uint8_t *__restrict__ iq, size_t n, size_t in_pitch, int ds,
+                                                    int rotate90, const int32_t *__restrict__ st_in,
+                                                    int32_t *__restrict__ st_out, int16_t *__restrict__ pcm,
+                                                    size_t out_pitch)
+{
+    __shared__ int xr[256], xj[256];
+    const size_t chan = blockIdx.y;
+    const uint8_t *x = iq + 2 * chan * in_pitch;
+    const int32_t *si = st_in + 5 * chan;
+    const int now_r = si[0], now_j = si[1], prev_index = si[2];
+    const long long m_total = ((long long)prev_index + (long long)n) / ds; // outputs of this call
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    // output m covers samples [m*ds - prev_index, (m+1)*ds - prev_index); output 0 also the carried partial sum
+    auto lowpassed = [&](long long mm, int &r, int &j) {
+        int sr = mm == 0 ? now_r : 0, sj = mm == 0 ? now_j : 0;
+        long long first = mm * ds - prev_index, last = first + ds;
+        rtlfm_sum(x, first < 0 ? 0 : first, last, rotate90, sr, sj);
+        r = (int)(int16_t)sr; // lowpassed[] is int16_t (rtl_fm.c:117,313-314)
+        j = (int)(int16_t)sj;
+    };
+    int ar = 0, aj = 0;
+    if (m < m_total) lowpassed(m, ar, aj);
+    xr[threadIdx.x] = ar;
+    xj[threadIdx.x] = aj;
+    __syncthreads();
+    if (m < m_total) {
+        int br, bj;
+        if (threadIdx.x > 0) { br = xr[threadIdx.x - 1]; bj = xj[threadIdx.x - 1]; }
+        else if (m == 0) { br = si[3]; bj = si[4]; }              // pre_r, pre_j (rtl_fm.c:523)
+        else lowpassed(m - 1, br, bj);                             // first thread of a later workgroup
+        bj = -bj;                                                  // multiply(a, conj b): rtl_fm.c:422-426,432
+        const int cr = ar * br - aj * bj, cj = aj * br + ar * bj;
+        const double angle = sdrx_atan2((double)cj, (double)cr);
+        pcm[chan * out_pitch + (size_t)m] = (int16_t)(int)(angle / 3.14159 * (1 << 14)); // rtl_fm.c:434
+        if (m == m_total - 1) { st_out[5 * chan + 3] = ar; st_out[5 * chan + 4] = aj; } // rtl_fm.c:543-544
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { // the samples after the last whole window stay in the partial sum
+        int sr = m_total == 0 ? now_r : 0, sj = m_total == 0 ? now_j : 0;
+        long long first = m_total * ds - prev_index;
+        rtlfm_sum(x, first < 0 ? 0 : first, (long long)n, rotate90, sr, sj);
+        st_out[5 * chan + 0] = sr;
+        st_out[5 * chan + 1] = sj;
+        st_out[5 * chan + 2] = (int32_t)(((long long)prev_index + (long long)n) % ds);
+        if (m_total == 0) { st_out[5 * chan + 3] = si[3]; st_out[5 * chan + 4] = si[4]; }
+    }
+}
+
+int launch_rtlfm(const uint8_t *iq, size_t n, size_t nchan, size_t in_pitch, int ds, int rotate90,
+                 const int32_t *st_in, int32_t *st_out, int16_t *pcm, size_t out_pitch, hipStream_t s)
+{
+    if (!iq || !st_in || !st_out || !pcm || ds < 1 || st_in == st_out) {
+        set_error("sdrx_rtlfm_dev: bad argument (downsample %d)", ds);
+        return SDRX_EINVAL;
+    }
+    if (nchan == 0) return SDRX_OK;
+    const size_t blocks = (n / (size_t)ds + 1 + 255) / 256; // prev_index < ds adds at most one output
+    if (blocks > 0x7fffffffULL || nchan > 65535) return SDRX_EUNSUPPORTED;
+    hipLaunchKernelGGL(rtlfm_kernel, dim3((unsigned)blocks, (unsigned)nchan), dim3(256), 0, s, iq, n, in_pitch, ds,
+                       rotate90, st_in, st_out, pcm, out_pitch);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }

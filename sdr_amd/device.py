@@ -124,6 +124,30 @@ def fm_demod(re, w1, w2, out, ds):
                "sdrx_fm_demod_dev")
 
 
+class RtlFm:
+    """rtl_fm's int16 chain (u8 bytes -> -127 -> boxcar decimate -> polar discriminant -> int16 pcm) over
+    `nchan` independent byte streams, state carried like struct demod_state (rtl_fm.c:113-147)."""
+
+    def __init__(self, nchan=1, downsample=10, rotate90=False, device="cuda"):
+        self.L = _lib.lib()
+        self.nchan, self.ds, self.rot = int(nchan), int(downsample), bool(rotate90)
+        self.state = [torch.zeros(self.nchan, 5, dtype=torch.int32, device=device) for _ in range(2)]
+        self.cur = 0
+        self.prev_index = 0
+
+    def demod(self, raw, pcm):
+        """raw: (nchan, n, 2) uint8; pcm: (nchan, >= (prev_index + n) // downsample) int16.  Returns the count."""
+        assert raw.dtype == torch.uint8 and raw.is_contiguous() and pcm.dtype == torch.int16
+        n = raw.shape[1]
+        _lib.check(self.L.sdrx_rtlfm_dev(_ptr(raw), n, self.nchan, n, self.ds, int(self.rot), _ptr(self.state[self.cur]),
+                                         _ptr(self.state[self.cur ^ 1]), _ptr(pcm), pcm.shape[1], _stream()),
+                   "sdrx_rtlfm_dev")
+        self.cur ^= 1
+        m = (self.prev_index + n) // self.ds
+        self.prev_index = (self.prev_index + n) % self.ds
+        return m
+
+
 class PskBank:
     """nchan independent BPSK or QPSK demodulators (BPSK.cpp:148-176 / QPSK.cpp:190-219), device resident."""
 

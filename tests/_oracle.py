@@ -22,6 +22,7 @@ BPSK, QPSK = 0, 1
 _f64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _u8 = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 _i16 = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+_i32 = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _u64 = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 _sz = C.c_size_t
 
@@ -90,6 +91,8 @@ def lib():
     L.orc_fm_discriminator.restype = None
     L.orc_fm_discriminator_i16.argtypes = [_i16, _sz, _i16, _i16, C.c_int]
     L.orc_fm_discriminator_i16.restype = None
+    L.orc_rtlfm_chain.argtypes = [_u8, _sz, C.c_int, C.c_int, _i32, _i16, C.c_int]
+    L.orc_rtlfm_chain.restype = _sz
     L.orc_decimate.argtypes = [_f64, _sz, _sz]
     L.orc_decimate.restype = _sz
     L.orc_upsample_fill_w_zeros.argtypes = [_f64, _sz, _f64, _sz, C.c_double]
@@ -203,6 +206,15 @@ def u8_to_iq(buf, bias=127.0, signed_char=False, rotate90=False):
     re, im = np.zeros(n), np.zeros(n)
     lib().orc_u8_to_iq(b, n, float(bias), int(bool(signed_char)), re, im)
     return re, im
+
+
+def rtlfm_chain(raw, downsample, st, rotate90=False, math_mode=MATH_SHARED):
+    """rtl_fm's int16 chain on raw bytes (n, 2); st = int32[5] carried state, updated in place"""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8).reshape(-1)
+    n = raw.size // 2
+    pcm = np.zeros(n // max(downsample, 1) + 2, dtype=np.int16)
+    m = lib().orc_rtlfm_chain(raw, n, int(downsample), int(bool(rotate90)), st, pcm, math_mode)
+    return pcm[:m]
 
 
 def fm_discriminator(re, im, pre=None, math_mode=MATH_SHARED):

@@ -421,6 +421,35 @@ def test_u8_ingest_f32():
     assert np.max(np.abs(o1[0].cpu().numpy() - yq) / sq) <= 1e-5
 
 
+@pytest.mark.parametrize("ds,rot", [(10, False), (10, True), (1, False), (7, True), (256, False)])
+def test_rtlfm_int16_chain(ds, rot):
+    """sdrx_rtlfm_dev = rtl_fm's callback conversion + low_pass + fm_demod (rtl_fm.c:303-323, 422-435, 518-546,
+    808-822) on raw bytes: int16 pcm identical to the oracle's restatement, 3 channels, ragged chunks whose
+    lengths are not multiples of the downsample factor (partial boxcar sums and pre_r/pre_j carried)."""
+    C_, n = 3, 100000
+    rng = np.random.default_rng(ds)
+    raw = rng.integers(0, 256, (C_, n, 2), dtype=np.uint8)
+    t = np.arange(n)
+    ph = 40 * np.sin(2 * np.pi * t / 4800.0)
+    raw[0, :, 0] = np.clip(np.round(127.4 + 110 * np.cos(ph)), 0, 255).astype(np.uint8)
+    raw[0, :, 1] = np.clip(np.round(127.4 + 110 * np.sin(ph)), 0, 255).astype(np.uint8)
+    fm = device.RtlFm(C_, ds, rot)
+    sts = [np.zeros(5, dtype=np.int32) for _ in range(C_)]
+    cuts = [0, 4 * 3, 4 * 3 + 4 * 2501, 4 * 3 + 4 * 2501 + 4 * 9973, n]  # multiples of 4 (rotate_90 works on 8-byte groups)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        x = torch.tensor(raw[:, lo:hi].copy(), device="cuda")
+        pcm = torch.zeros(C_, (hi - lo) // ds + 2, dtype=torch.int16, device="cuda")
+        m = fm.demod(x, pcm)
+        got = pcm.cpu().numpy()
+        for c in range(C_):
+            want = O.rtlfm_chain(raw[c, lo:hi], ds, sts[c], rot)
+            assert want.size == m
+            assert np.array_equal(got[c, :m], want), (c, lo, hi)
+        st_dev = fm.state[fm.cur].cpu().numpy()
+        for c in range(C_):
+            assert np.array_equal(st_dev[c], sts[c]), (c, lo, hi)
+
+
 # =============================================================================== fp32 twins
 
 @pytest.mark.parametrize("D,T", [(1, 64), (4, 129), (10, 64), (8, 64), (5, 33), (12, 100), (3, 64), (100, 64)])
