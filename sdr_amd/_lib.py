@@ -115,6 +115,10 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -m sdr_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
         )
+    # torch first: it ships its own HIP runtime, and one process must not initialise two of them.  With
+    # torch's loaded, libsdrx.so binds to it (same soname); loaded the other way round, the second
+    # runtime to start sees no device.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the library does not export it

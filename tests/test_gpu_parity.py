@@ -506,6 +506,31 @@ def test_f32_twins_within_1e5(D, T):
                 assert np.array_equal(bits[c][sure], (env >= 80.0).astype(np.uint8)[sure]), (D, T, c, call)
 
 
+def test_empty_and_tiny_inputs():
+    """Edge cases the reference's loops accept silently: no channels, no samples, fewer samples than the
+    decimation factor or than the taps -- through every FIR kernel family; state is carried unchanged by
+    an empty call and correctly by tiny ones."""
+    for D, T in ((10, 64), (1, 64), (4, 129), (100, 64)):
+        err, taps = O.fir_design(O.LPF, T, 2.4e6, 1.0e5)
+        re, im = fm_iq(300, seed=5)
+        ch = host.Chain(taps, D)
+        hI, hQ, pre = np.zeros(T - 1), np.zeros(T - 1), np.zeros(2)
+        for lo, hi in ((0, 0), (0, 1), (1, 1), (1, 3), (3, 3 + D - 1 if D > 1 else 4), (120, 300), (300, 300)):
+            r, i = re[lo:hi].copy(), im[lo:hi].copy()
+            got = ch.fir_fmdisc(r, i)
+            want = _oracle_chain_disc(taps, r, i, D, hI, hQ, pre) if hi > lo else np.zeros(0)
+            assert got.size == want.size and np.array_equal(got, want), (D, T, lo, hi)
+    dev_ch = device.FirChain(taps, nchan=4, decim=10)
+    x = torch.zeros(4, 0, 2, dtype=torch.float64, device="cuda")
+    out = torch.zeros(4, 1, dtype=torch.float64, device="cuda")
+    dev_ch.fir_fmdisc(x, out)  # n = 0: a no-op that keeps the state
+    torch.cuda.synchronize()
+    f = host.Filter(O.LPF, 64, 2.0e6, 1.0e5)
+    f.execute(np.zeros(0))
+    out = np.zeros(0, dtype=np.uint8)
+    assert host.AM().demodulate(np.zeros(0), np.zeros(0), out, 0, 8) == 0
+
+
 def test_fast_fma_within_tolerance():
     """fast_fma = 1 fuses multiply-add: not bit-exact; bound |err| <= 1e-12 * sum|h||x| (north_star's fp64 tolerance)."""
     err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
