@@ -152,6 +152,74 @@ __global__ void __launch_bounds__(FSK_NT) fsk_corr_kernel(const double *__restri
     if (tid < bits_here) out[bit0 + tid] = (op1 > op2) ? 1 : 0; // FM.h:139 (repaired)
 }
 
+// The same correlator for ds >= 16, one WAVE per 64 bits and no workgroup barrier: the wave walks the
+// windows from their last sample down in chunks of 16 samples per bit.  A chunk is 64 runs of 128
+// contiguous bytes, loaded 4 runs per instruction into registers one chunk AHEAD of the arithmetic,
+// transposed through the wave's own LDS slice (pitch 17 doubles: conflict-free both ways), and each
+// lane then adds its bit's 16 products in the reference's order.  Taps come by scalar loads.
+constexpr int FSKW_KC = 16;
+
+__global__ void __launch_bounds__(256) fsk_corr_wave_kernel(const double *__restrict__ x, const double *__restrict__ w1,
+                                                            const double *__restrict__ w2, uint8_t *__restrict__ out,
+                                                            size_t nbits, unsigned ds)
+{
+    constexpr int KC = FSKW_KC, PITCH = KC + 1;
+    __shared__ double smem[4 * 64 * PITCH];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *lds = smem + wave * 64 * PITCH;
+    const size_t bit0 = ((size_t)blockIdx.x * 4 + wave) * 64;
+    if (bit0 >= nbits) return;
+    const unsigned nchunks = (ds + KC - 1) / KC;
+    // lane's element i of a chunk: row 4 i + lane / 16, sample lane % 16 of the chunk
+    const unsigned k_ld = lane & 15, row_ld = lane >> 4;
+    const double *xrow[KC]; // row bases of the 16 rows this lane loads from
+    bool row_ok[KC];
+#pragma unroll
+    for (int i = 0; i < KC; i++) {
+        const size_t b = bit0 + 4 * i + row_ld;
+        row_ok[i] = b < nbits;
+        xrow[i] = x + (row_ok[i] ? b : bit0) * (size_t)ds + k_ld;
+    }
+    double regs[KC];
+    auto load_chunk = [&](unsigned chunk) {
+        const unsigned c_lo = chunk * KC;
+        const bool k_ok = c_lo + k_ld < ds; // only the window's top chunk can be partial
+#pragma unroll
+        for (int i = 0; i < KC; i++) regs[i] = (k_ok && row_ok[i]) ? xrow[i][c_lo] : 0.0;
+    };
+    load_chunk(nchunks - 1);
+    double op1 = 0.0, op2 = 0.0;
+    for (int chunk = (int)nchunks - 1; chunk >= 0; chunk--) {
+#pragma unroll
+        for (int i = 0; i < KC; i++) lds[(4 * i + row_ld) * PITCH + k_ld] = regs[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (chunk > 0) load_chunk((unsigned)chunk - 1); // in flight during this chunk's arithmetic
+        const unsigned c_lo = (unsigned)chunk * KC;
+        const double *row = lds + lane * PITCH;
+        if (c_lo + KC <= ds) {
+            double v[KC];
+#pragma unroll
+            for (int k = 0; k < KC; k++) v[k] = row[k];
+#pragma unroll
+            for (int k = KC - 1; k >= 0; k--) { // last sample first: FM.h:94-100
+                op1 += v[k] * w1[c_lo + k];
+                op2 += v[k] * w2[c_lo + k];
+            }
+        } else {
+            for (int k = (int)(ds - c_lo) - 1; k >= 0; k--) {
+                const double v = row[k];
+                op1 += v * w1[c_lo + k];
+                op2 += v * w2[c_lo + k];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // these reads stay above the next chunk's writes
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (bit0 + lane < nbits) out[bit0 + lane] = (op1 > op2) ? 1 : 0; // FM.h:139 (repaired)
+}
+
 int launch_fm_demod(const double *re, const double *w1, const double *w2, uint8_t *out, size_t n, size_t ds,
                     hipStream_t s)
 {
@@ -162,6 +230,14 @@ int launch_fm_demod(const double *re, const double *w1, const double *w2, uint8_
     if (ds > 0x7fffffffu) return SDRX_EUNSUPPORTED;
     size_t nbits = n / ds; // FM.h:114
     if (nbits == 0) return SDRX_OK;
+    if (ds >= (size_t)FSKW_KC) {
+        const size_t wblocks = (nbits + 255) / 256;
+        if (wblocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
+        hipLaunchKernelGGL(fsk_corr_wave_kernel, dim3((unsigned)wblocks), dim3(256), 0, s, re, w1, w2, out, nbits,
+                           (unsigned)ds);
+        SDRX_HIP(hipGetLastError());
+        return SDRX_OK;
+    }
     size_t blocks = (nbits + FSK_NT - 1) / FSK_NT;
     if (blocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
     hipLaunchKernelGGL(fsk_corr_kernel, dim3((unsigned)blocks), dim3(FSK_NT), 0, s, re, w1, w2, out, nbits,

@@ -176,7 +176,7 @@ def test_fm_golden(golden):
     assert np.array_equal(out2, G(golden, "TEST_FM__FM__ModDemodResampled__outputStream"))
 
 
-@pytest.mark.parametrize("ds", [1, 2, 31, 32, 33, 100, 333, 2000])
+@pytest.mark.parametrize("ds", [1, 2, 15, 16, 17, 31, 32, 33, 100, 333, 2000])
 def test_fm_demod_vs_oracle(ds):
     """FM<T>::demodulate (FM.h:83-148): bits identical on noisy FSK and on pure noise (ties matter)."""
     rng = np.random.default_rng(ds)
