@@ -13,6 +13,8 @@
 // from the number of independent channels.  cos/sin are include/sdrx_math.h on both sides.
 #include "sdrx_internal.h"
 
+#include <cstdlib>
+
 #include "../../include/sdrx_math.h"
 
 namespace sdrx {
@@ -221,6 +223,80 @@ __global__ void __launch_bounds__(64) psk_loops_kernel(double2 *__restrict__ mf,
     }
 }
 
+// Both loops of a full demodulation on TWO waves of one workgroup (two SIMDs of a CU): wave 0 runs the
+// timing loop over block j of SPLIT_KB samples into an LDS ring, wave 1 the carrier loop over block
+// j-1 out of it, one s_barrier per block.  With one channel per lane a bank of 2^14 channels is only
+// 256 waves on 1024 SIMDs, and each loop alone is issue-bound on its SIMD: splitting them uses a
+// second SIMD per 64 channels.  Same per-sample arithmetic as psk_loops_kernel.
+constexpr int SPLIT_KB = 16;
+
+template <int KIND>
+__global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__restrict__ mf, size_t m, size_t nchan,
+                                                              size_t pitch, sdrx_psk_state *__restrict__ states,
+                                                              uint8_t *__restrict__ dec, size_t out_pitch)
+{
+    __shared__ double2 ring[2][SPLIT_KB][64];
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t c0 = (size_t)blockIdx.x * 64 + lane;
+    const bool active = c0 < nchan;
+    const size_t c = active ? c0 : nchan - 1; // idle lanes shadow the last channel and store nothing
+    sdrx_psk_state *st = states + c;
+    const double2 *x = mf + c * pitch;
+    uint8_t *d = dec + c * out_pitch;
+    const size_t nblocks = (m + SPLIT_KB - 1) / SPLIT_KB;
+
+    TimingState t = {st->nco_delay, st->reg_mu, st->reg_Q, st->reg_I, st->mu_delay,
+                     {st->iq_d[0], st->iq_d[1], st->iq_d[2], st->iq_d[3], st->iq_d[4]},
+                     {st->ii_d[0], st->ii_d[1], st->ii_d[2], st->ii_d[3], st->ii_d[4]},
+                     st->g1, st->g2, st->g3, st->g4, st->lf_x, st->lf_y};
+    PhaseState p = {st->dds_delay, st->plf_x, st->plf_y, 0.0, 0.0, 0.0};
+    double2 nxt[SPLIT_KB];
+    if (role == 0) {
+#pragma unroll
+        for (int k = 0; k < SPLIT_KB; k++) nxt[k] = ((size_t)k < m) ? x[k] : make_double2(0.0, 0.0);
+    }
+    for (size_t j = 0; j <= nblocks; j++) {
+        if (role == 0) {
+            if (j < nblocks) {
+                double2 cur[SPLIT_KB];
+#pragma unroll
+                for (int k = 0; k < SPLIT_KB; k++) cur[k] = nxt[k];
+                const size_t nb = (j + 1) * SPLIT_KB; // the next block's samples land during this block's arithmetic
+#pragma unroll
+                for (int k = 0; k < SPLIT_KB; k++) nxt[k] = (nb + k < m) ? x[nb + k] : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int k = 0; k < SPLIT_KB; k++) {
+                    double re = cur[k].x, im = cur[k].y;
+                    if (j * SPLIT_KB + k < m) timing_step(t, re, im); // uniform: m is the same for all lanes
+                    ring[j & 1][k][lane] = make_double2(re, im);
+                }
+            }
+        } else if (j >= 1) {
+            const size_t i0 = (j - 1) * SPLIT_KB;
+#pragma unroll
+            for (int k = 0; k < SPLIT_KB; k++) {
+                const double2 v = ring[(j - 1) & 1][k][lane];
+                if (i0 + k < m) {
+                    const int decision = phase_step<KIND>(p, v.x, v.y);
+                    if ((k & 1) == 0 && active) d[(i0 + k) >> 1] = (uint8_t)decision; // SPLIT_KB is even: parity of k
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    if (role == 0) {
+        st->nco_delay = t.nco; st->reg_mu = t.reg_mu; st->reg_Q = t.reg_Q; st->reg_I = t.reg_I; st->mu_delay = t.mu_delay;
+        st->iq_d[0] = t.iq.d1; st->iq_d[1] = t.iq.d2; st->iq_d[2] = t.iq.d3; st->iq_d[3] = t.iq.d4; st->iq_d[4] = t.iq.d5;
+        st->ii_d[0] = t.ii.d1; st->ii_d[1] = t.ii.d2; st->ii_d[2] = t.ii.d3; st->ii_d[3] = t.ii.d4; st->ii_d[4] = t.ii.d5;
+        st->g1 = t.g1; st->g2 = t.g2; st->g3 = t.g3; st->g4 = t.g4;
+        st->lf_x = t.lf_x; st->lf_y = t.lf_y;
+    } else {
+        st->dds_delay = p.dds_delay; st->plf_x = p.plf_x; st->plf_y = p.plf_y;
+    }
+}
+
 int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch, sdrx_psk_state *states,
                      uint8_t *decisions, size_t out_pitch, int run_timing, int run_phase, hipStream_t s)
 {
@@ -231,6 +307,20 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
     if (nchan == 0 || m == 0 || (!run_timing && !run_phase)) return SDRX_OK;
     size_t blocks = (nchan + 63) / 64;
     if (blocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
+    // few channels (fewer waves than SIMDs): give each 64-channel group a second SIMD
+    const char *se = getenv("SDRX_PSK_SPLIT"); // "0" / "1" force one form (tests, experiments)
+    const int split_env = se ? atoi(se) : -1;
+    const bool split = split_env >= 0 ? split_env != 0 : blocks <= 2048;
+    if (run_timing && run_phase && split) {
+        if (kind == SDRX_BPSK)
+            hipLaunchKernelGGL(psk_loops_split_kernel<SDRX_BPSK>, dim3((unsigned)blocks), dim3(128), 0, s,
+                               (const double2 *)mf_iq, m, nchan, mf_pitch, states, decisions, out_pitch);
+        else
+            hipLaunchKernelGGL(psk_loops_split_kernel<SDRX_QPSK>, dim3((unsigned)blocks), dim3(128), 0, s,
+                               (const double2 *)mf_iq, m, nchan, mf_pitch, states, decisions, out_pitch);
+        SDRX_HIP(hipGetLastError());
+        return SDRX_OK;
+    }
     typedef void (*fn_t)(double2 *, size_t, size_t, size_t, sdrx_psk_state *, uint8_t *, size_t);
     fn_t fn;
     if (kind == SDRX_BPSK)

@@ -693,6 +693,35 @@ def test_psk_bank_multichannel_device():
                 assert np.array_equal(mine, sts[c].loop_state())
 
 
+def test_psk_loops_one_wave_and_two_wave_forms_agree(monkeypatch):
+    """psk_loops_kernel (both loops interleaved in one wave) and psk_loops_split_kernel (timing and carrier
+    loop on two waves through an LDS ring) are picked by channel count; forced either way they give the
+    same decisions and state, and both match the oracle (odd lengths, 3 blocks, 70 channels)."""
+    nchan = 70
+    for n in (4096, 4096 - 8 * 5):
+        iqs = [psk_test_signal(O.BPSK if c % 2 else O.QPSK, n // 8, seed=300 + c, phase_deg=45.0 * c, snr_db=15.0,
+                               timing_offset=c % 4) for c in range(nchan)]
+        for kind, lk in ((O.QPSK, _lib.QPSK), (O.BPSK, _lib.BPSK)):
+            x = torch.tensor(np.stack([np.asarray(z).reshape(-1, 2) for z in iqs]), device="cuda")
+            res = {}
+            for force in ("0", "1"):
+                monkeypatch.setenv("SDRX_PSK_SPLIT", force)
+                b = device.PskBank(lk, nchan, n)
+                outs = []
+                for _ in range(3):
+                    o = torch.zeros(nchan, b.n_dec, dtype=torch.uint8, device="cuda")
+                    b.demod(x, o)
+                    outs.append(o.cpu().numpy())
+                res[force] = (outs, b.states.cpu().numpy())
+            for a, bb in zip(res["0"][0], res["1"][0]):
+                assert np.array_equal(a, bb), (kind, n)
+            assert np.array_equal(res["0"][1], res["1"][1]), (kind, n)
+            st = O.psk_new(kind, math_mode=O.MATH_SHARED)
+            for blk in range(3):
+                want = O.psk_demodulate(st, iqs[0])
+                assert np.array_equal(res["1"][0][blk][0][: want.size], want), (kind, n, blk)
+
+
 def test_psk_stage_entry_points_equal_the_fused_call():
     """sdrx_psk_matched_filter_dev -> sdrx_psk_loops_dev (timing, then carrier, as separate launches and as
     one) -> sdrx_psk_ambiguity_dev give the decisions and loop state of sdrx_psk_demod_dev, bit for bit."""
