@@ -506,6 +506,54 @@ def test_f32_twins_within_1e5(D, T):
                 assert np.array_equal(bits[c][sure], (env >= 80.0).astype(np.uint8)[sure]), (D, T, c, call)
 
 
+def test_fir_shapes_fuzz():
+    """80 seeded random shapes through the device layer: taps 1..200, decimation 1..40 (every kernel family
+    and every hand-over between them: systolic D in {5,8,10,12} with few and with too many stages,
+    register blockings, gather tiles), 1..5 channels, ragged lengths, 3 calls with carried state, a random
+    layout and epilogue each -- all bit-identical to the oracle."""
+    rng = np.random.default_rng(20260101)
+    for case in range(80):
+        T = int(rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 64, 65, 100, 129, 200]))
+        D = int(rng.choice([1, 2, 3, 4, 5, 5, 6, 8, 8, 10, 10, 12, 12, 16, 25, 40]))
+        C_ = int(rng.integers(1, 6))
+        epi = ("store", "am", "disc")[int(rng.integers(0, 3))]
+        layout = ("split", "inter")[int(rng.integers(0, 2))]
+        err, taps = O.fir_design(O.LPF if T > 1 else O.HPF, T, 2.4e6, 1.0e5)
+        assert err == 0
+        lens = [int(rng.integers(1, 6000)) for _ in range(3)]
+        data = [[fm_iq(n, seed=1000 * case + 10 * k + c) for c in range(C_)] for k, n in enumerate(lens)]
+        ch = device.FirChain(taps, nchan=C_, decim=D)
+        H = max(T - 1, 1)
+        hist = [(np.zeros(H), np.zeros(H), np.zeros(2)) for _ in range(C_)]
+        fir_i = [O.Fir(O.LPF if T > 1 else O.HPF, T, 2.4e6, 1.0e5) for _ in range(C_)]
+        fir_q = [O.Fir(O.LPF if T > 1 else O.HPF, T, 2.4e6, 1.0e5) for _ in range(C_)]
+        for k, n in enumerate(lens):
+            re = torch.tensor(np.stack([d[0] for d in data[k]]), device="cuda")
+            im = torch.tensor(np.stack([d[1] for d in data[k]]), device="cuda")
+            x = (re, im) if layout == "split" else torch.stack([re, im], dim=-1).contiguous()
+            n_out = (n + D - 1) // D
+            tag = (case, T, D, C_, epi, layout, k, n)
+            if epi == "store":
+                o0 = torch.zeros(C_, n_out, dtype=torch.float64, device="cuda")
+                o1 = torch.zeros(C_, n_out, dtype=torch.float64, device="cuda")
+                ch.fir(x, o0, o1)
+                for c in range(C_):
+                    assert np.array_equal(o0[c].cpu().numpy(), fir_i[c].execute(data[k][c][0], fast=True)[::D]), tag
+                    assert np.array_equal(o1[c].cpu().numpy(), fir_q[c].execute(data[k][c][1], fast=True)[::D]), tag
+            elif epi == "am":
+                bits = torch.zeros(C_, n_out, dtype=torch.uint8, device="cuda")
+                ch.fir_am(x, bits)
+                for c in range(C_):
+                    want = _oracle_chain_am(taps, data[k][c][0], data[k][c][1], D, hist[c][0], hist[c][1])
+                    assert np.array_equal(bits[c].cpu().numpy(), want), tag
+            else:
+                ang = torch.zeros(C_, n_out, dtype=torch.float64, device="cuda")
+                ch.fir_fmdisc(x, ang)
+                for c in range(C_):
+                    want = _oracle_chain_disc(taps, data[k][c][0], data[k][c][1], D, hist[c][0], hist[c][1], hist[c][2])
+                    assert np.array_equal(ang[c].cpu().numpy(), want), tag
+
+
 def test_empty_and_tiny_inputs():
     """Edge cases the reference's loops accept silently: no channels, no samples, fewer samples than the
     decimation factor or than the taps -- through every FIR kernel family; state is carried unchanged by
