@@ -196,6 +196,11 @@ void sdrx_chain_destroy(sdrx_chain_t *c);
 void sdrx_chain_reset(sdrx_chain_t *c);
 size_t sdrx_chain_fir_am(sdrx_chain_t *c, const double *re, const double *im, size_t n, uint8_t *bits);
 size_t sdrx_chain_fir_fmdisc(sdrx_chain_t *c, const double *re, const double *im, size_t n, double *angle);
+/* The same two chains fed with the radio's raw bytes (uint8 {I,Q} pairs as rtlsdr_read_async delivers them):
+ * x = byte - bias on the device (bias 127: rtlsdr_receiver.cpp:1587-1588; 127.4 with SDRX_U8_SIGNED_CHAR:
+ * Baseband_Stream.cpp:128-148), an eighth of the PCIe traffic of the fp64 entry points. */
+size_t sdrx_chain_fir_am_u8(sdrx_chain_t *c, const uint8_t *iq_u8, size_t n, double bias, int flags, uint8_t *bits);
+size_t sdrx_chain_fir_fmdisc_u8(sdrx_chain_t *c, const uint8_t *iq_u8, size_t n, double bias, int flags, double *angle);
 
 typedef struct sdrx_psk sdrx_psk_t;
 sdrx_psk_t *sdrx_psk_create(int kind, uint64_t bpsk_uw, const double *qpsk_uw64, size_t uw_len);

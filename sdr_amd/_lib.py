@@ -82,6 +82,8 @@ SIGNATURES = {
     "sdrx_chain_reset": (None, [_vp]),
     "sdrx_chain_fir_am": (_sz, [_vp, _vp, _vp, _sz, _vp]),
     "sdrx_chain_fir_fmdisc": (_sz, [_vp, _vp, _vp, _sz, _vp]),
+    "sdrx_chain_fir_am_u8": (_sz, [_vp, _vp, _sz, C.c_double, C.c_int, _vp]),
+    "sdrx_chain_fir_fmdisc_u8": (_sz, [_vp, _vp, _sz, C.c_double, C.c_int, _vp]),
     "sdrx_psk_create": (_vp, [C.c_int, C.c_uint64, _vp, _sz]),
     "sdrx_psk_destroy": (None, [_vp]),
     "sdrx_psk_get_state": (None, [_vp, C.POINTER(PskState)]),

@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
+#include <vector>
 #include <vector>
 
 namespace sdrx {
@@ -99,6 +101,29 @@ struct Staging {
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// memcpy between caller memory and pinned staging; large blocks are split over a few threads (one
+// core moves about 10 GB/s, well under what the PCIe link then carries)
+static void staged_copy(void *dst, const void *src, size_t bytes)
+{
+    const size_t piece = (size_t)8 << 20;
+    unsigned nt = (unsigned)(bytes / piece);
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned cap = hw ? (hw < 8 ? hw : 8) : 4;
+    if (nt > cap) nt = cap;
+    if (nt < 2) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / nt) + 63) & ~(size_t)63;
+    for (unsigned t = 0; t < nt; t++) {
+        const size_t lo = (size_t)t * per, hi = (t + 1 == nt) ? bytes : ((size_t)(t + 1) * per < bytes ? (size_t)(t + 1) * per : bytes);
+        if (lo >= hi) break;
+        th.emplace_back([=] { memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+    }
+    for (auto &x : th) x.join();
+}
 
 } // namespace sdrx
 
@@ -397,7 +422,7 @@ extern "C" int sdrx_fir_execute(sdrx_fir_t *f, double *buf, size_t n)
     if (rc) return rc;
     rc = f->out.ensure(bytes);
     if (rc) return rc;
-    memcpy(f->in.host, buf, bytes);
+    staged_copy(f->in.host, buf, bytes);
     SDRX_HIP(hipMemcpyAsync(f->in.dev, f->in.host, bytes, hipMemcpyHostToDevice, f->stream));
     sdrx_fir_job j;
     memset(&j, 0, sizeof(j));
@@ -420,7 +445,7 @@ extern "C" int sdrx_fir_execute(sdrx_fir_t *f, double *buf, size_t n)
     f->cur ^= 1;
     SDRX_HIP(hipMemcpyAsync(f->out.host, f->out.dev, bytes, hipMemcpyDeviceToHost, f->stream));
     SDRX_HIP(hipStreamSynchronize(f->stream));
-    memcpy(buf, f->out.host, bytes);
+    staged_copy(buf, f->out.host, bytes);
     return SDRX_OK;
 }
 
@@ -452,8 +477,8 @@ extern "C" size_t sdrx_am_demodulate(const double *re, const double *im, uint8_t
         printf("[HIP][sdrx_am_demodulate] Error! %s\n", g_err); // print-and-continue: am.cu:143-146
         return 0;
     }
-    memcpy(c.a.host, re, bytes);
-    memcpy(c.b.host, im, bytes);
+    staged_copy(c.a.host, re, bytes);
+    staged_copy(c.b.host, im, bytes);
     bool ok = hipMemcpyAsync(c.a.dev, c.a.host, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
               hipMemcpyAsync(c.b.dev, c.b.host, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
               launch_am_demod((double *)c.a.dev, (double *)c.b.dev, (uint8_t *)c.c.dev, n, ds, c.stream) == SDRX_OK &&
@@ -463,7 +488,7 @@ extern "C" size_t sdrx_am_demodulate(const double *re, const double *im, uint8_t
         printf("[HIP][sdrx_am_demodulate] Error! %s\n", g_err);
         return 0;
     }
-    memcpy(out, c.c.host, n_out);
+    staged_copy(out, c.c.host, n_out);
     return n_out; // out_index of AM.h:76
 }
 
@@ -506,7 +531,7 @@ extern "C" size_t sdrx_fm_demodulate(double rx_rate, double mark, double space, 
         printf("[HIP][sdrx_fm_demodulate] Error! %s\n", g_err);
         return 0;
     }
-    memcpy(c.a.host, re, bytes);
+    staged_copy(c.a.host, re, bytes);
     memcpy(c.b.host, w1.data(), wbytes);
     memcpy((char *)c.b.host + wbytes, w2.data(), wbytes);
     bool ok = hipMemcpyAsync(c.a.dev, c.a.host, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
@@ -519,7 +544,7 @@ extern "C" size_t sdrx_fm_demodulate(double rx_rate, double mark, double space, 
         printf("[HIP][sdrx_fm_demodulate] Error! %s\n", g_err);
         return 0;
     }
-    memcpy(out, c.c.host, nbits);
+    staged_copy(out, c.c.host, nbits);
     return nbits; // FM.h:147
 }
 
@@ -540,6 +565,20 @@ extern "C" void sdrx_fm_modulate(double tx_rate, double mark, double space, cons
 }
 
 // ---- FIR + demod chains on host buffers
+// One stream through FIR (+ demod) from host buffers.  Long calls are cut into chunks of CHAIN_CHUNK
+// samples (a multiple of the decimation factor), two staging slots: while the GPU copies in, filters
+// and copies out chunk k, the host fills the pinned buffer of chunk k+1 and drains chunk k-1 --
+// pinned memory stays bounded however long the call is.  The FIR state carries from chunk to chunk
+// exactly as it does from call to call.
+static const size_t CHAIN_CHUNK = (size_t)1 << 22;
+
+struct ChainSlot {
+    Staging in0, in1, out;
+    hipEvent_t done = nullptr;
+    size_t n = 0, n_out = 0, out_off = 0; // what is in flight in this slot
+    bool busy = false;
+};
+
 struct sdrx_chain {
     int T = 0;
     unsigned D = 1;
@@ -547,7 +586,7 @@ struct sdrx_chain {
     double *d_state[2] = {nullptr, nullptr};
     int cur = 0;
     hipStream_t stream = nullptr;
-    Staging re, im, out;
+    ChainSlot slot[2];
 };
 
 extern "C" sdrx_chain_t *sdrx_chain_create(const double *taps, int num_taps, unsigned decim)
@@ -562,7 +601,8 @@ extern "C" sdrx_chain_t *sdrx_chain_create(const double *taps, int num_taps, uns
               hipMemcpy(c->d_taps, taps, num_taps * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
     for (int i = 0; ok && i < 2; i++)
         ok = hipMalloc((void **)&c->d_state[i], sd * sizeof(double)) == hipSuccess &&
-             hipMemset(c->d_state[i], 0, sd * sizeof(double)) == hipSuccess;
+             hipMemset(c->d_state[i], 0, sd * sizeof(double)) == hipSuccess &&
+             hipEventCreateWithFlags(&c->slot[i].done, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         set_error("sdrx_chain_create: device allocation failed");
         sdrx_chain_destroy(c);
@@ -576,11 +616,13 @@ extern "C" void sdrx_chain_destroy(sdrx_chain_t *c)
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_taps) (void)hipFree(c->d_taps);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
         if (c->d_state[i]) (void)hipFree(c->d_state[i]);
-    c->re.release();
-    c->im.release();
-    c->out.release();
+        c->slot[i].in0.release();
+        c->slot[i].in1.release();
+        c->slot[i].out.release();
+        if (c->slot[i].done) (void)hipEventDestroy(c->slot[i].done);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -592,51 +634,109 @@ extern "C" void sdrx_chain_reset(sdrx_chain_t *c)
     for (int i = 0; i < 2; i++) (void)hipMemset(c->d_state[i], 0, sdrx_fir_state_doubles(c->T) * sizeof(double));
 }
 
-static size_t chain_run(sdrx_chain *c, const double *re, const double *im, size_t n, void *out, size_t out_elem,
-                        FirEpilogue epi)
+// re/im: split fp64 rails; or u8 != nullptr: raw interleaved bytes (SDRX_IQ_U8) with bias / flags
+static size_t chain_run(sdrx_chain *c, const double *re, const double *im, const uint8_t *u8, double u8_bias, int u8_flags,
+                        size_t n, void *out, size_t out_elem, FirEpilogue epi)
 {
-    if (!c || !re || !im || !out || n == 0) return 0;
-    const size_t bytes = n * sizeof(double), n_out = (n + c->D - 1) / c->D;
-    if (c->re.ensure(bytes) || c->im.ensure(bytes) || c->out.ensure(n_out * out_elem + 8)) return 0;
-    memcpy(c->re.host, re, bytes);
-    memcpy(c->im.host, im, bytes);
-    if (hipMemcpyAsync(c->re.dev, c->re.host, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-        hipMemcpyAsync(c->im.dev, c->im.host, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    if (!c || !out || n == 0 || (!u8 && (!re || !im))) return 0;
+    if (u8 && (u8_flags & SDRX_U8_ROTATE90)) {
+        set_error("sdrx_chain_*_u8: rotate_90 restarts at every call; use the device layer for it");
         return 0;
-    sdrx_fir_job j;
-    memset(&j, 0, sizeof(j));
-    j.layout = SDRX_IQ_SPLIT;
-    j.in0 = c->re.dev;
-    j.in1 = c->im.dev;
-    j.n = n;
-    j.nchan = 1;
-    j.in_pitch = n;
-    j.taps = c->d_taps;
-    j.num_taps = c->T;
-    j.decim = c->D;
-    j.state_in = c->d_state[c->cur];
-    j.state_out = c->d_state[c->cur ^ 1];
-    j.state_pitch = sdrx_fir_state_doubles(c->T);
-    j.out0 = c->out.dev;
-    j.out_pitch = n_out;
-    j.stream = c->stream;
-    if (launch_fir(&j, epi) != SDRX_OK) return 0;
-    c->cur ^= 1;
-    if (hipMemcpyAsync(c->out.host, c->out.dev, n_out * out_elem, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
+    }
+    const size_t chunk = CHAIN_CHUNK - CHAIN_CHUNK % c->D; // whole decimation groups: chunk outputs abut
+    const size_t in_elem = u8 ? 2 : sizeof(double);
+    size_t done_out = 0;
+    bool failed = false;
+    auto drain = [&](ChainSlot &sl) { // wait for the slot's chunk and hand its outputs to the caller
+        if (!sl.busy) return;
+        if (hipEventSynchronize(sl.done) != hipSuccess) failed = true;
+        if (!failed) staged_copy((char *)out + sl.out_off * out_elem, sl.out.host, sl.n_out * out_elem);
+        done_out += sl.n_out;
+        sl.busy = false;
+    };
+    size_t k = 0;
+    for (size_t off = 0; off < n && !failed; off += chunk, k++) {
+        ChainSlot &sl = c->slot[k & 1];
+        drain(sl);
+        const size_t m = (n - off) < chunk ? (n - off) : chunk, m_out = (m + c->D - 1) / c->D;
+        if (sl.in0.ensure(m * in_elem) || (!u8 && sl.in1.ensure(m * in_elem)) || sl.out.ensure(m_out * out_elem + 8)) {
+            failed = true;
+            break;
+        }
+        if (u8) {
+            staged_copy(sl.in0.host, u8 + 2 * off, m * 2);
+        } else {
+            staged_copy(sl.in0.host, re + off, m * in_elem);
+            staged_copy(sl.in1.host, im + off, m * in_elem);
+        }
+        if (hipMemcpyAsync(sl.in0.dev, sl.in0.host, m * in_elem, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            (!u8 && hipMemcpyAsync(sl.in1.dev, sl.in1.host, m * in_elem, hipMemcpyHostToDevice, c->stream) != hipSuccess)) {
+            failed = true;
+            break;
+        }
+        sdrx_fir_job j;
+        memset(&j, 0, sizeof(j));
+        j.layout = u8 ? SDRX_IQ_U8 : SDRX_IQ_SPLIT;
+        j.in0 = sl.in0.dev;
+        j.in1 = u8 ? nullptr : sl.in1.dev;
+        j.u8_bias = u8_bias;
+        j.u8_flags = u8_flags;
+        j.n = m;
+        j.nchan = 1;
+        j.in_pitch = m;
+        j.taps = c->d_taps;
+        j.num_taps = c->T;
+        j.decim = c->D;
+        j.state_in = c->d_state[c->cur];
+        j.state_out = c->d_state[c->cur ^ 1];
+        j.state_pitch = sdrx_fir_state_doubles(c->T);
+        j.out0 = sl.out.dev;
+        j.out_pitch = m_out;
+        j.stream = c->stream;
+        if (launch_fir(&j, epi) != SDRX_OK) {
+            failed = true;
+            break;
+        }
+        c->cur ^= 1;
+        if (hipMemcpyAsync(sl.out.host, sl.out.dev, m_out * out_elem, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipEventRecord(sl.done, c->stream) != hipSuccess) {
+            failed = true;
+            break;
+        }
+        sl.n = m;
+        sl.n_out = m_out;
+        sl.out_off = off / c->D;
+        sl.busy = true;
+    }
+    drain(c->slot[k & 1]); // oldest first
+    drain(c->slot[(k + 1) & 1]);
+    if (failed) {
+        (void)hipStreamSynchronize(c->stream);
+        c->slot[0].busy = c->slot[1].busy = false;
         return 0;
-    memcpy(out, c->out.host, n_out * out_elem);
-    return n_out;
+    }
+    return done_out;
 }
 
 extern "C" size_t sdrx_chain_fir_am(sdrx_chain_t *c, const double *re, const double *im, size_t n, uint8_t *bits)
 {
-    return chain_run(c, re, im, n, bits, 1, EPI_AM);
+    return chain_run(c, re, im, nullptr, 0.0, 0, n, bits, 1, EPI_AM);
 }
 
 extern "C" size_t sdrx_chain_fir_fmdisc(sdrx_chain_t *c, const double *re, const double *im, size_t n, double *angle)
 {
-    return chain_run(c, re, im, n, angle, sizeof(double), EPI_DISC);
+    return chain_run(c, re, im, nullptr, 0.0, 0, n, angle, sizeof(double), EPI_DISC);
+}
+
+extern "C" size_t sdrx_chain_fir_am_u8(sdrx_chain_t *c, const uint8_t *iq_u8, size_t n, double bias, int flags, uint8_t *bits)
+{
+    return chain_run(c, nullptr, nullptr, iq_u8, bias, flags, n, bits, 1, EPI_AM);
+}
+
+extern "C" size_t sdrx_chain_fir_fmdisc_u8(sdrx_chain_t *c, const uint8_t *iq_u8, size_t n, double bias, int flags,
+                                           double *angle)
+{
+    return chain_run(c, nullptr, nullptr, iq_u8, bias, flags, n, angle, sizeof(double), EPI_DISC);
 }
 
 // ---- PSK objects
@@ -718,7 +818,7 @@ extern "C" size_t sdrx_psk_demodulate(sdrx_psk_t *p, const double *iq, size_t n,
     if (p->in.ensure(in_bytes) || p->mid.ensure(sdrx_psk_work_bytes(n, 1)) || p->out.ensure(nd + 8) ||
         p->hits.ensure(PSK_MAX_HITS * sizeof(uint64_t)))
         return 0;
-    memcpy(p->in.host, iq, in_bytes);
+    staged_copy(p->in.host, iq, in_bytes);
     if (hipMemcpyAsync(p->in.dev, p->in.host, in_bytes, hipMemcpyHostToDevice, p->stream) != hipSuccess) return 0;
     unsigned char *w = (unsigned char *)p->mid.dev;
     double *mf = (double *)w;
@@ -748,7 +848,7 @@ extern "C" size_t sdrx_psk_decode_pulse_shape(sdrx_psk_t *p, const double *iq, s
     if (m == 0) return 0;
     const size_t in_bytes = n * 2 * sizeof(double);
     if (p->in.ensure(in_bytes) || p->mid.ensure(sdrx_psk_work_bytes(n, 1))) return 0;
-    memcpy(p->in.host, iq, in_bytes);
+    staged_copy(p->in.host, iq, in_bytes);
     if (hipMemcpyAsync(p->in.dev, p->in.host, in_bytes, hipMemcpyHostToDevice, p->stream) != hipSuccess) return 0;
     unsigned char *w = (unsigned char *)p->mid.dev;
     double *mf = (double *)w;
@@ -836,8 +936,8 @@ extern "C" int sdrx_psk_modulate(int kind, const uint8_t *sym, size_t len, doubl
     const size_t n = 8 * len, bytes = n * sizeof(double);
     int rc = c.ready();
     if (rc || (rc = c.a.ensure(bytes)) || (rc = c.b.ensure(bytes)) || (rc = c.c.ensure(len + 8))) return rc;
-    memcpy(c.a.host, out_real, bytes); // prior contents take part beyond the byte-count memset (BPSK.cpp:131)
-    if (kind == SDRX_QPSK) memcpy(c.b.host, out_imag, bytes);
+    staged_copy(c.a.host, out_real, bytes); // prior contents take part beyond the byte-count memset (BPSK.cpp:131)
+    if (kind == SDRX_QPSK) staged_copy(c.b.host, out_imag, bytes);
     memcpy(c.c.host, sym, len);
     SDRX_HIP(hipMemcpyAsync(c.a.dev, c.a.host, bytes, hipMemcpyHostToDevice, c.stream));
     if (kind == SDRX_QPSK) SDRX_HIP(hipMemcpyAsync(c.b.dev, c.b.host, bytes, hipMemcpyHostToDevice, c.stream));
@@ -848,8 +948,8 @@ extern "C" int sdrx_psk_modulate(int kind, const uint8_t *sym, size_t len, doubl
     SDRX_HIP(hipMemcpyAsync(c.a.host, c.a.dev, bytes, hipMemcpyDeviceToHost, c.stream));
     if (kind == SDRX_QPSK) SDRX_HIP(hipMemcpyAsync(c.b.host, c.b.dev, bytes, hipMemcpyDeviceToHost, c.stream));
     SDRX_HIP(hipStreamSynchronize(c.stream));
-    memcpy(out_real, c.a.host, bytes);
-    if (kind == SDRX_QPSK) memcpy(out_imag, c.b.host, bytes);
+    staged_copy(out_real, c.a.host, bytes);
+    if (kind == SDRX_QPSK) staged_copy(out_imag, c.b.host, bytes);
     return SDRX_OK;
 }
 
@@ -939,8 +1039,8 @@ extern "C" double am_gpu_demodulation(int RADIO_ID, double *real, double *imag, 
     }
     Radio &r = g_am[RADIO_ID];
     const size_t bytes = number_of_points * sizeof(double);
-    memcpy(r.h_re, real, bytes);
-    memcpy(r.h_im, imag, bytes);
+    staged_copy(r.h_re, real, bytes);
+    staged_copy(r.h_im, imag, bytes);
     bool ok = hipMemcpyAsync(r.d_re, r.h_re, bytes, hipMemcpyHostToDevice, r.stream) == hipSuccess &&
               hipMemcpyAsync(r.d_im, r.h_im, bytes, hipMemcpyHostToDevice, r.stream) == hipSuccess &&
               hipStreamSynchronize(r.stream) == hipSuccess;
@@ -952,7 +1052,7 @@ extern "C" double am_gpu_demodulation(int RADIO_ID, double *real, double *imag, 
     ok = ok && hipMemcpyAsync(r.h_out, r.d_out, nout, hipMemcpyDeviceToHost, r.stream) == hipSuccess &&
          hipStreamSynchronize(r.stream) == hipSuccess;
     if (!ok) printf("[HIP][am_gpu_demodulation] Error!\n"); // am.cu:143-146
-    else memcpy(output, r.h_out, nout);
+    else staged_copy(output, r.h_out, nout);
     return std::chrono::duration_cast<std::chrono::duration<double>>(t2 - t1).count();
 }
 
@@ -997,7 +1097,7 @@ extern "C" double fm_gpu_demodulation(int RADIO_ID, double *real, double *imag, 
     }
     Radio &r = g_fm[RADIO_ID];
     const size_t bytes = number_of_points * sizeof(double);
-    memcpy(r.h_re, real, bytes);
+    staged_copy(r.h_re, real, bytes);
     bool ok = hipMemcpyAsync(r.d_re, r.h_re, bytes, hipMemcpyHostToDevice, r.stream) == hipSuccess &&
               hipStreamSynchronize(r.stream) == hipSuccess;
     clk::time_point t1 = clk::now();
@@ -1008,7 +1108,7 @@ extern "C" double fm_gpu_demodulation(int RADIO_ID, double *real, double *imag, 
     ok = ok && hipMemcpyAsync(r.h_out, r.d_out, nout, hipMemcpyDeviceToHost, r.stream) == hipSuccess &&
          hipStreamSynchronize(r.stream) == hipSuccess;
     if (!ok) printf("[HIP][fm_gpu_demodulation] Error!\n"); // fm.cu:159-162
-    else memcpy(output, r.h_out, nout);
+    else staged_copy(output, r.h_out, nout);
     return std::chrono::duration_cast<std::chrono::duration<double>>(t2 - t1).count();
 }
 
@@ -1021,8 +1121,8 @@ extern "C" int32_t ones_zeros_demodulation(double *real, double *imag, size_t nu
         printf("[HIP][ones_zeros_demodulation] Error!\n");
         return 0;
     }
-    memcpy(c.a.host, real, bytes);
-    memcpy(c.b.host, imag, bytes);
+    staged_copy(c.a.host, real, bytes);
+    staged_copy(c.b.host, imag, bytes);
     bool ok = hipMemcpyAsync(c.a.dev, c.a.host, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
               hipMemcpyAsync(c.b.dev, c.b.host, bytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
               launch_ones_zeros((double *)c.a.dev, (double *)c.b.dev, number_of_points, (int32_t *)c.c.dev,

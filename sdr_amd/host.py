@@ -224,3 +224,19 @@ class Chain:
         out = np.zeros((n + self.decim - 1) // self.decim + 8)
         m = self._L.sdrx_chain_fir_fmdisc(self._h, _p(_f64(re)), _p(_f64(im)), n, _p(out))
         return out[:m]
+
+    def fir_am_u8(self, raw, bias=127.0, signed_char=False):
+        """raw: (n, 2) uint8 radio bytes, converted on the device (x = byte - bias)"""
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        n = raw.size // 2
+        out = np.zeros((n + self.decim - 1) // self.decim + 8, dtype=np.uint8)
+        m = self._L.sdrx_chain_fir_am_u8(self._h, _p(raw), n, float(bias), _lib.U8_SIGNED_CHAR if signed_char else 0, _p(out))
+        return out[:m]
+
+    def fir_fmdisc_u8(self, raw, bias=127.0, signed_char=False):
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        n = raw.size // 2
+        out = np.zeros((n + self.decim - 1) // self.decim + 8)
+        m = self._L.sdrx_chain_fir_fmdisc_u8(self._h, _p(raw), n, float(bias), _lib.U8_SIGNED_CHAR if signed_char else 0,
+                                             _p(out))
+        return out[:m]

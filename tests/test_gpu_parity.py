@@ -506,6 +506,40 @@ def test_f32_twins_within_1e5(D, T):
                 assert np.array_equal(bits[c][sure], (env >= 80.0).astype(np.uint8)[sure]), (D, T, c, call)
 
 
+def test_host_chain_long_call_is_chunked_and_u8_entry_points():
+    """The host layer cuts a long call into 2^22-sample chunks on two staging slots (state carried from
+    chunk to chunk): 2 * 2^22 + 12345 samples in one call equal the oracle's single pass; the raw-byte
+    entry points equal the oracle's conversion + chain; a second call continues the stream."""
+    err, taps = O.fir_design(O.LPF, 64, 2.4e6, 1.0e5)
+    n, D = 2 * (1 << 22) + 12345, 10
+    raw = np.random.default_rng(77).integers(0, 256, (n, 2), dtype=np.uint8)
+    ph = 25 * np.sin(2 * np.pi * np.arange(n) / 3000.0)
+    raw[:, 0] = np.clip(np.round(127.0 + 90 * np.cos(ph)) + (raw[:, 0] & 7), 0, 255).astype(np.uint8)
+    raw[:, 1] = np.clip(np.round(127.0 + 90 * np.sin(ph)) + (raw[:, 1] & 7), 0, 255).astype(np.uint8)
+    re, im = O.u8_to_iq(raw)
+    hI, hQ, pre = np.zeros(63), np.zeros(63), np.zeros(2)
+    aI, aQ = np.zeros(63), np.zeros(63)
+    want_ang = _oracle_chain_disc(taps, re, im, D, hI, hQ, pre)
+    want_bits = _oracle_chain_am(taps, re, im, D, aI, aQ)
+    c1, c2, c3, c4 = host.Chain(taps, D), host.Chain(taps, D), host.Chain(taps, D), host.Chain(taps, D)
+    assert np.array_equal(c1.fir_fmdisc(re, im), want_ang)
+    assert np.array_equal(c2.fir_am(re, im), want_bits)
+    assert np.array_equal(c3.fir_fmdisc_u8(raw), want_ang)
+    assert np.array_equal(c4.fir_am_u8(raw), want_bits)
+    # continue all four streams with a short second call
+    m = 50000
+    want_ang2 = _oracle_chain_disc(taps, re[:m], im[:m], D, hI, hQ, pre)
+    want_bits2 = _oracle_chain_am(taps, re[:m], im[:m], D, aI, aQ)
+    assert np.array_equal(c1.fir_fmdisc(re[:m].copy(), im[:m].copy()), want_ang2)
+    assert np.array_equal(c3.fir_fmdisc_u8(raw[:m].copy()), want_ang2)
+    assert np.array_equal(c2.fir_am(re[:m].copy(), im[:m].copy()), want_bits2)
+    assert np.array_equal(c4.fir_am_u8(raw[:m].copy()), want_bits2)
+    # Baseband_Stream::load_buffer's conversion through the host entry point
+    r2, i2 = O.u8_to_iq(raw[:m], 127.4, signed_char=True)
+    w = _oracle_chain_disc(taps, r2, i2, D, np.zeros(63), np.zeros(63), np.zeros(2))
+    assert np.array_equal(host.Chain(taps, D).fir_fmdisc_u8(raw[:m].copy(), 127.4, signed_char=True), w)
+
+
 def test_fir_shapes_fuzz():
     """80 seeded random shapes through the device layer: taps 1..200, decimation 1..40 (every kernel family
     and every hand-over between them: systolic D in {5,8,10,12} with few and with too many stages,
