@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--shard", action="store_true",
                     help="cfg4: strong scaling -- the 1024 channels (2^20 samples each) are block-partitioned over the "
                          "ranks (sdr_amd.shard.partition) instead of every rank running its own 1024")
+    ap.add_argument("--decim", type=int, default=10, help="cfg2/cfg4 only: another decimation factor (exploration; the "
+                                                          "BASELINE workload is 10)")
+    ap.add_argument("--taps", type=int, default=64, help="cfg2/cfg4 only: another filter length (exploration)")
     ap.add_argument("--fast-fma", action="store_true")
     ap.add_argument("--mfma", action="store_true", help="cfg5: fp64 MFMA Toeplitz formulation (fast mode 2)")
     args = ap.parse_args()
@@ -131,7 +134,7 @@ def main():
     def as_input(x):  # synthetic samples are integers in [-127, 127]: byte = x + 127
         return (x + 127.0).to(torch.uint8).contiguous() if u8 else x.to(tdt)
     if wl in ("cfg2", "cfg4"):
-        D, T, Fs = 10, 64, 2.4e6
+        D, T, Fs = args.decim, args.taps, 2.4e6
         taps = lpf_taps(T, Fs, 1.0e5)
         if wl == "cfg2":
             nchan, n = 1, 1 << (args.log2n or 28)
@@ -150,7 +153,8 @@ def main():
         units = nchan * n
         bytes_per_sample = in_bytes + (4.0 if f32 else 8.0) / D
         kernel = "fir_systolic_kernel<D=10, IQ_INTERLEAVED, EPI_DISC>"
-        cfg = {"workload": f"{wl}: Filter(LPF,64,2.4e6,1e5) on I,Q -> decimate 10 -> phase-difference discriminator",
+        kernel = kernel if D == 10 else "fir_* (launch_fir's choice)"
+        cfg = {"workload": f"{wl}: Filter(LPF,{T},2.4e6,1e5) on I,Q -> decimate {D} -> phase-difference discriminator",
                "channels_per_gpu": nchan, "samples_per_channel_per_step": n,
                "layout": lay,
                "parallelism": f"{n_gpus} independent stream set(s), no collective"}

@@ -221,7 +221,7 @@ def _oracle_chain_disc(taps, re, im, D, hI, hQ, pre):
     return out[:m]
 
 
-@pytest.mark.parametrize("ds", [1, 5, 8, 10, 12, 100])
+@pytest.mark.parametrize("ds", [1, 5, 6, 8, 10, 12, 16, 20, 25, 100])
 def test_chain_fir_am_host(ds):
     """BASELINE config 1: Filter(LPF,64,2e6,1e5) on I and Q, AM::demodulate(ds); streamed in chunks."""
     err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
@@ -238,10 +238,11 @@ def test_chain_fir_am_host(ds):
 
 
 @pytest.mark.parametrize("D,T", [(10, 64), (1, 64), (2, 33), (3, 64), (4, 129), (7, 20), (16, 64), (64, 64), (100, 64), (10, 1), (10, 2),
-                                 (5, 33), (5, 61), (5, 64), (8, 7), (8, 64), (8, 97), (12, 64), (12, 100), (12, 144), (12, 145), (10, 120), (10, 121)])
+                                 (5, 33), (5, 61), (5, 64), (8, 7), (8, 64), (8, 97), (12, 64), (12, 100), (12, 144), (12, 145), (10, 120), (10, 121),
+                                 (5, 80), (5, 81), (6, 64), (6, 97), (16, 64), (16, 3), (20, 64), (20, 200), (25, 64), (25, 129)])
 def test_chain_fir_fmdisc_host(D, T):
     """BASELINE config 2: LPF -> decimate by D -> phase-difference discriminator; every FIR register
-    blocking (R = 8, 4, 2, 1), gather tiles (D >= T), the systolic kernel (D in 5, 8, 10, 12: one stage,
+    blocking (R = 8, 4, 2, 1), gather tiles (D >= T), the systolic kernel (D in 5, 6, 8, 10, 12, 16, 20, 25: one stage,
     whole and partial last stages, and filters long enough to fall back to workgroup tiles) and the
     state carry across ragged chunks."""
     err, taps = O.fir_design(O.LPF, T, 2.4e6, 1.0e5)
@@ -290,7 +291,7 @@ def test_chain_device_layouts_multichannel():
         assert np.array_equal(bits[c].cpu().numpy(), _oracle_chain_am(taps, res[c], ims[c], 1, np.zeros(63), np.zeros(63)))
 
 
-@pytest.mark.parametrize("D", [5, 8, 10, 12])
+@pytest.mark.parametrize("D", [5, 6, 8, 10, 12, 16, 20, 25])
 def test_decimating_fir_store_all_layouts(D):
     """sdrx_fir_dev with decimation (Filter on each rail, then decimate<T>, Resample.h:33-52): real,
     split and interleaved inputs through the systolic kernel, 3 channels, two calls with carried state;
@@ -548,7 +549,7 @@ def test_fir_shapes_fuzz():
     rng = np.random.default_rng(20260101)
     for case in range(80):
         T = int(rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 64, 65, 100, 129, 200]))
-        D = int(rng.choice([1, 2, 3, 4, 5, 5, 6, 8, 8, 10, 10, 12, 12, 16, 25, 40]))
+        D = int(rng.choice([1, 2, 3, 4, 5, 5, 6, 8, 8, 10, 10, 12, 12, 16, 20, 25, 40]))
         C_ = int(rng.integers(1, 6))
         epi = ("store", "am", "disc")[int(rng.integers(0, 3))]
         layout = ("split", "inter")[int(rng.integers(0, 2))]
