@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--decim", type=int, default=10, help="cfg2/cfg4 only: another decimation factor (exploration; the "
                                                           "BASELINE workload is 10)")
     ap.add_argument("--taps", type=int, default=64, help="cfg2/cfg4 only: another filter length (exploration)")
+    ap.add_argument("--channels", type=int, default=0, help="cfg3 only: channel count (power of two; default 2^14; "
+                                                            "the total stays 2^26 samples)")
     ap.add_argument("--fast-fma", action="store_true")
     ap.add_argument("--mfma", action="store_true", help="cfg5: fp64 MFMA Toeplitz formulation (fast mode 2)")
     args = ap.parse_args()
@@ -196,7 +198,8 @@ def main():
                "channels_per_gpu": nchan, "samples_per_channel_per_step": n, "layout": "real fp64",
                "parallelism": f"{n_gpus} x {nchan} independent channels, no collective"}
     else:  # cfg3
-        nchan, n = 1 << 14, 1 << ((args.log2n or 26) - 14)
+        lc = (args.channels or (1 << 14)).bit_length() - 1
+        nchan, n = 1 << lc, 1 << ((args.log2n or 26) - lc)
         g = torch.Generator(device=dev).manual_seed(7 + rank)
         x = torch.randn(nchan, n, 2, generator=g, device=dev, dtype=torch.float64) * 0.3
         bank = device.PskBank(_lib.QPSK, nchan, n, device=dev)

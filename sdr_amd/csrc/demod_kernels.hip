@@ -269,13 +269,15 @@ __device__ __forceinline__ void rtlfm_sum(const uint8_t *__restrict__ x, long lo
     }
 }
 
-__global__ void __launch_bounds__(256) rtlfm_kernel(const uint8_t *__restrict__ iq, size_t n, size_t in_pitch, int ds,
+__global__ void __launch_bounds__(256) rtlfm_kernel(const uint8_t *__restrict__ iq, size_t n, size_t nchan,
+                                                    size_t in_pitch, int ds,
                                                     int rotate90, const int32_t *__restrict__ st_in,
                                                     int32_t *__restrict__ st_out, int16_t *__restrict__ pcm,
                                                     size_t out_pitch)
 {
     __shared__ int xr[256], xj[256];
-    const size_t chan = blockIdx.y;
+    const size_t chan = (size_t)blockIdx.z * 65535u + blockIdx.y; // grid.y is limited to 65535
+    if (chan >= nchan) return;                                     // a whole workgroup
     const uint8_t *x = iq + 2 * chan * in_pitch;
     const int32_t *si = st_in + 5 * chan;
     const int now_r = si[0], now_j = si[1], prev_index = si[2];
@@ -325,8 +327,9 @@ int launch_rtlfm(const uint8_t *iq, size_t n, size_t nchan, size_t in_pitch, int
     }
     if (nchan == 0) return SDRX_OK;
     const size_t blocks = (n / (size_t)ds + 1 + 255) / 256; // prev_index < ds adds at most one output
-    if (blocks > 0x7fffffffULL || nchan > 65535) return SDRX_EUNSUPPORTED;
-    hipLaunchKernelGGL(rtlfm_kernel, dim3((unsigned)blocks, (unsigned)nchan), dim3(256), 0, s, iq, n, in_pitch, ds,
+    if (blocks > 0x7fffffffULL || nchan > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
+    const unsigned gy = nchan < 65535 ? (unsigned)nchan : 65535u, gz = (unsigned)((nchan + 65534) / 65535);
+    hipLaunchKernelGGL(rtlfm_kernel, dim3((unsigned)blocks, gy, gz), dim3(256), 0, s, iq, n, nchan, in_pitch, ds,
                        rotate90, st_in, st_out, pcm, out_pitch);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;

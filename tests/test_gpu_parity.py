@@ -589,6 +589,36 @@ def test_fir_shapes_fuzz():
                     assert np.array_equal(ang[c].cpu().numpy(), want), tag
 
 
+def test_more_channels_than_a_grid_dimension():
+    """70000 channels (> 65535, the limit of grid.y) through the workgroup-tile kernel, the systolic kernel
+    and the rtl_fm chain: a few channels spot-checked against the oracle, all equal to their duplicates."""
+    C_, n = 70000, 96
+    rng = np.random.default_rng(8)
+    base = rng.integers(-127, 128, (7, n, 2)).astype(np.float64)
+    idx = np.arange(C_) % 7
+    x = torch.tensor(base, device="cuda")[torch.tensor(idx, device="cuda")].contiguous()
+    for D, T in ((1, 8), (10, 16)):
+        err, taps = O.fir_design(O.LPF, T, 2.4e6, 1.0e5)
+        ch = device.FirChain(taps, nchan=C_, decim=D)
+        n_out = (n + D - 1) // D
+        o0 = torch.zeros(C_, n_out, dtype=torch.float64, device="cuda")
+        o1 = torch.zeros(C_, n_out, dtype=torch.float64, device="cuda")
+        ch.fir(x, o0, o1)
+        got = o0.cpu().numpy()
+        for c in (0, 1, 6, 65534, 65535, 65536, 69999):
+            want = O.Fir(O.LPF, T, 2.4e6, 1.0e5).execute(base[idx[c], :, 0], fast=True)[::D]
+            assert np.array_equal(got[c], want), (D, T, c)
+        assert np.array_equal(got[7:], got[:-7])  # channel c + 7 carries the same data as channel c
+    raw = torch.tensor((base + 127).astype(np.uint8), device="cuda")[torch.tensor(idx, device="cuda")].contiguous()
+    fm = device.RtlFm(C_, 4)
+    pcm = torch.zeros(C_, n // 4 + 2, dtype=torch.int16, device="cuda")
+    m = fm.demod(raw, pcm)
+    got = pcm.cpu().numpy()[:, :m]
+    st = np.zeros(5, dtype=np.int32)
+    assert np.array_equal(got[69999], O.rtlfm_chain((base[idx[69999]] + 127).astype(np.uint8), 4, st))
+    assert np.array_equal(got[7:], got[:-7])
+
+
 def test_empty_and_tiny_inputs():
     """Edge cases the reference's loops accept silently: no channels, no samples, fewer samples than the
     decimation factor or than the taps -- through every FIR kernel family; state is carried unchanged by
