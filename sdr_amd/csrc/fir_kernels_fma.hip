@@ -1,3 +1,4 @@
+// fir_kernels_fma.hip -- the fused multiply-add (fast mode 1) instances of the fp64 FIR kernels; see
 // fir_kernels.hip -- time-tiled, register-blocked FIR for gfx950 with fused demod epilogues.
 //
 // Replaces Filter::do_sample / Filter::execute (RadioNode/third-party/FIR-filter-class/filt.cpp:248-273)
@@ -36,22 +37,10 @@ namespace sdrx {
 
 #define FT double
 #define SDRX_FNS f64
-#define SDRX_FIR_PART 1 /* exact kernels + launcher; the fma kernels are fir_kernels_fma.hip */
+#define SDRX_FIR_PART 2
 #include "fir_impl.inc"
 #undef SDRX_FIR_PART
 #undef FT
 #undef SDRX_FNS
-
-namespace f32 { int launch_fir_impl(const sdrx_fir_job *job, FirEpilogue epi); } // fir_kernels_f32.hip
-
-int launch_fir(const sdrx_fir_job *job, FirEpilogue epi)
-{
-    if (job && job->dtype == SDRX_F32) return f32::launch_fir_impl(job, epi);
-    if (job && job->dtype != SDRX_F64) {
-        set_error("sdrx_fir*_dev: unknown dtype %d", job->dtype);
-        return SDRX_EINVAL;
-    }
-    return f64::launch_fir_impl(job, epi);
-}
 
 } // namespace sdrx
