@@ -76,6 +76,40 @@ def cpu_baseline_cfg2(taps, D, sample_log2=28):
             "sample": f"2^{sample_log2} samples of the cfg2 chain (oracle/sdr_oracle.c, gcc -O2 -ffp-contract=off), {dt:.1f} s"}
 
 
+def cpu_baseline_all_cores(taps, D, threads, sample_log2=25):
+    """The same port on `threads` host threads, one independent stream each (ctypes releases the GIL):
+    what SURVEY 8d calls CPU-all-cores.  Reported next to cpu_baseline, never the target."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    L = O.lib()
+    n = 1 << sample_log2
+    T = taps.size
+    rng = np.random.default_rng(2)
+    work = []
+    for _ in range(threads):
+        work.append((rng.integers(-127, 128, n).astype(np.float64), rng.integers(-127, 128, n).astype(np.float64),
+                     np.zeros(T), np.zeros(T), np.zeros(2), np.zeros(n // D + 2)))
+
+    def run(w):
+        re, im, srI, srQ, pre, out = w
+        L.orc_fir_execute(taps, T, srI, re, n)
+        L.orc_fir_execute(taps, T, srQ, im, n)
+        m = L.orc_decimate(re, n, D)
+        L.orc_decimate(im, n, D)
+        L.orc_fm_discriminator(re, im, m, pre, out, O.MATH_LIBM)
+
+    ths = [threading.Thread(target=run, args=(w,)) for w in work]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": threads * n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} independent streams of 2^{sample_log2} samples, one thread each, {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,6 +302,8 @@ def main():
         }
         if n_gpus == 1 and not args.no_cpu and wl == "cfg2" and not f32 and not u8:
             res["cpu_baseline"] = cpu_baseline_cfg2(taps, 10)
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(taps, 10, threads)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

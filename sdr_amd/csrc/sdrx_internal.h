@@ -54,7 +54,6 @@ int launch_psk_ambiguity_hits(int kind, uint8_t *decisions, size_t m, size_t nch
 int launch_psk_modulate(int kind, const uint8_t *sym, size_t len, double *out_re, double *out_im, size_t zero_prefix,
                         hipStream_t s);
 const double *psk_mf_taps_dev(); // RRC reversed (h[k] = RRC[128-k]), device resident, created on first use
-const double *zero_state_dev(size_t doubles); // device buffer of >= `doubles` zeros (grown on demand, never written)
 extern const double RRC_COEFF[129];
 
 } // namespace sdrx
