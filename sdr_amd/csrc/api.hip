@@ -639,11 +639,11 @@ static size_t chain_run(sdrx_chain *c, const double *re, const double *im, const
                         size_t n, void *out, size_t out_elem, FirEpilogue epi)
 {
     if (!c || !out || n == 0 || (!u8 && (!re || !im))) return 0;
-    if (u8 && (u8_flags & SDRX_U8_ROTATE90)) {
-        set_error("sdrx_chain_*_u8: rotate_90 restarts at every call; use the device layer for it");
-        return 0;
-    }
-    const size_t chunk = CHAIN_CHUNK - CHAIN_CHUNK % c->D; // whole decimation groups: chunk outputs abut
+    // whole decimation groups, so that chunk outputs abut, and whole groups of 4 samples, so that rotate_90
+    // (which restarts at every CALL, Baseband_Stream.cpp:103-126) sees the same phase in every chunk
+    size_t group = c->D;
+    while (group % 4) group += c->D; // lcm(D, 4)
+    const size_t chunk = CHAIN_CHUNK < group ? group : CHAIN_CHUNK - CHAIN_CHUNK % group;
     const size_t in_elem = u8 ? 2 : sizeof(double);
     size_t done_out = 0;
     bool failed = false;

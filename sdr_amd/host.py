@@ -225,18 +225,22 @@ class Chain:
         m = self._L.sdrx_chain_fir_fmdisc(self._h, _p(_f64(re)), _p(_f64(im)), n, _p(out))
         return out[:m]
 
-    def fir_am_u8(self, raw, bias=127.0, signed_char=False):
+    @staticmethod
+    def _u8_flags(signed_char, rotate90):
+        return (_lib.U8_SIGNED_CHAR if signed_char else 0) | (_lib.U8_ROTATE90 if rotate90 else 0)
+
+    def fir_am_u8(self, raw, bias=127.0, signed_char=False, rotate90=False):
         """raw: (n, 2) uint8 radio bytes, converted on the device (x = byte - bias)"""
         raw = np.ascontiguousarray(raw, dtype=np.uint8)
         n = raw.size // 2
         out = np.zeros((n + self.decim - 1) // self.decim + 8, dtype=np.uint8)
-        m = self._L.sdrx_chain_fir_am_u8(self._h, _p(raw), n, float(bias), _lib.U8_SIGNED_CHAR if signed_char else 0, _p(out))
+        m = self._L.sdrx_chain_fir_am_u8(self._h, _p(raw), n, float(bias), self._u8_flags(signed_char, rotate90), _p(out))
         return out[:m]
 
-    def fir_fmdisc_u8(self, raw, bias=127.0, signed_char=False):
+    def fir_fmdisc_u8(self, raw, bias=127.0, signed_char=False, rotate90=False):
         raw = np.ascontiguousarray(raw, dtype=np.uint8)
         n = raw.size // 2
         out = np.zeros((n + self.decim - 1) // self.decim + 8)
-        m = self._L.sdrx_chain_fir_fmdisc_u8(self._h, _p(raw), n, float(bias), _lib.U8_SIGNED_CHAR if signed_char else 0,
+        m = self._L.sdrx_chain_fir_fmdisc_u8(self._h, _p(raw), n, float(bias), self._u8_flags(signed_char, rotate90),
                                              _p(out))
         return out[:m]

@@ -535,6 +535,12 @@ def test_host_chain_long_call_is_chunked_and_u8_entry_points():
     assert np.array_equal(c3.fir_fmdisc_u8(raw[:m].copy()), want_ang2)
     assert np.array_equal(c2.fir_am(re[:m].copy(), im[:m].copy()), want_bits2)
     assert np.array_equal(c4.fir_am_u8(raw[:m].copy()), want_bits2)
+    # load_buffer_and_rotate90 over a call longer than two chunks, D = 3 (chunks must stay whole groups of 4 samples)
+    err3, taps3 = O.fir_design(O.LPF, 33, 2.4e6, 1.0e5)
+    n4 = n - n % 4
+    r3, i3 = O.u8_to_iq(raw[:n4], 127.4, signed_char=True, rotate90=True)
+    w3 = _oracle_chain_disc(taps3, r3, i3, 3, np.zeros(32), np.zeros(32), np.zeros(2))
+    assert np.array_equal(host.Chain(taps3, 3).fir_fmdisc_u8(raw[:n4].copy(), 127.4, signed_char=True, rotate90=True), w3)
     # Baseband_Stream::load_buffer's conversion through the host entry point
     r2, i2 = O.u8_to_iq(raw[:m], 127.4, signed_char=True)
     w = _oracle_chain_disc(taps, r2, i2, D, np.zeros(63), np.zeros(63), np.zeros(2))
