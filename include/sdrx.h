@@ -129,6 +129,22 @@ int sdrx_fm_demod_dev(const double *re, const double *w1, const double *w2, uint
 int sdrx_rtlfm_dev(const uint8_t *iq_u8, size_t n, size_t nchan, size_t in_pitch, int downsample, int rotate90,
                    const int32_t *state_in, int32_t *state_out, int16_t *pcm, size_t out_pitch, void *stream);
 
+/* The bit-domain back end of the receive path: what RtlSdr_Receiver::deserializeData (rtlsdr_receiver.cpp:2197-2230)
+ * does with PacketFramer<T>::deserialize (network/PacketFramer.h:424-513), RingBuffer<T> and crc8 (crc/crc8.cpp), on
+ * `nchan` independent bit streams (one byte per bit, as the demodulators write them).  The n bits of a call are the ring
+ * buffer's content.  Per channel: events in the order the reference would emit them (at most max_events recorded, all
+ * counted), the 250 data bytes of every valid packet in payloads[(chan * max_events + k) * 250], and
+ * summary[4 * chan + {0,1,2}] = {events, bits consumed = where the ring buffer's front would stand, calls that
+ * returned 0}: the caller feeds bits[consumed .. n) again in front of the next bits. */
+typedef struct sdrx_frame_event {
+    int64_t pos;      /* index of the unique word's first bit */
+    int32_t kind;     /* 1 valid packet, 2 length > 250, 3 crc mismatch (the reference's return -1 cases) */
+    uint8_t len, crc; /* the header's length and crc fields */
+    uint8_t pad[2];
+} sdrx_frame_event;
+int sdrx_deframe_dev(const uint8_t *bits, size_t n, size_t nchan, size_t in_pitch, int crc_enable, sdrx_frame_event *events,
+                     uint8_t *payloads, size_t max_events, uint64_t *summary, void *stream);
+
 /* PSK loop state of one channel: the reference's public loop structs (BPSK.h:130-276) flattened. */
 typedef struct sdrx_psk_state {
     double nco_delay, reg_mu, reg_Q, reg_I, mu_delay; /* NcoControlVariables.delay, Register_*, muDelay */

@@ -17,6 +17,9 @@
 #include <streams/QPSK.h>
 #include <DigitalSignalProcessing/Resample.h>
 #include <common/BBP_Block.h>
+#include <common/RingBuffer.h>
+#include <crc/crc8.h>
+#include <network/PacketFramer.h>
 
 extern "C" {
 
@@ -177,6 +180,65 @@ void ref_qpsk_state(void *h, double *s, int32_t *cc)
     cc[1] = b->m_phase_ambiguity_cc_090.value();
     cc[2] = b->m_phase_ambiguity_cc_180.value();
     cc[3] = b->m_phase_ambiguity_cc_270.value();
+}
+
+// ---- crc8 / PacketFramer over a RingBuffer, driven like RtlSdr_Receiver::deserializeData
+// (rtlsdr_receiver.cpp:2197-2230; that loop is Qt application code and is restated here as the harness)
+uint8_t ref_crc8(uint8_t *message, size_t length)
+{
+    crc8 c;
+    return c.getCRC(message, length);
+}
+
+int ref_frame(uint8_t *data, size_t length, int crc_enable, uint8_t *bits_out)
+{
+    PacketFramer<uint8_t> framer;
+    framer.checkCRC(crc_enable != 0);
+    BBP_Block block(PacketFramer<uint8_t>::MAX_PKT_SIZE_BITS);
+    block.n_points = 0;
+    int r = framer.serialize(data, length, &block);
+    if (r > 0)
+        for (int i = 0; i < r; i++) bits_out[i] = (uint8_t)block.points[i].real();
+    return r;
+}
+
+void ref_deframe(const uint8_t *bits, size_t n, int crc_enable, size_t max_events, int64_t *ev_pos, int32_t *ev_kind,
+                 uint8_t *ev_len, uint8_t *ev_crc, uint8_t *payload, uint64_t *summary)
+{
+    PacketFramer<uint8_t> framer;
+    framer.checkCRC(crc_enable != 0);
+    RingBuffer<uint8_t> rb((int)n + 1);
+    rb.append(bits, n);
+    uint8_t pkt[256];
+    uint64_t nev = 0, zero_returns = 0;
+    size_t front = 0; // bits removed so far
+    while (rb.count() > PacketFramer<uint8_t>::MAX_PKT_SIZE_BITS) {
+        bool vp = false, vc = false, vh = false;
+        int bad = 0;
+        size_t before = rb.count();
+        int r = framer.deserialize(rb, pkt, 250, vp, vc, vh, bad);
+        front += before - rb.count();
+        if (r > 0 || r == -1) {
+            uint8_t len = PacketFramer<uint8_t>::ToByte(rb, PacketFramer<uint8_t>::LENGTH_POS);
+            uint8_t crc = PacketFramer<uint8_t>::ToByte(rb, PacketFramer<uint8_t>::CRC_POS);
+            if (nev < max_events) {
+                ev_pos[nev] = (int64_t)front;
+                ev_kind[nev] = r > 0 ? 1 : (len > 250 ? 2 : 3);
+                ev_len[nev] = len;
+                ev_crc[nev] = (r > 0 || len <= 250) ? crc : 0;
+                if (r > 0) memcpy(payload + 250 * nev, pkt, 250);
+            }
+            nev++;
+            size_t k = r > 0 ? (size_t)r * 8 : 1;
+            rb.remove(k);
+            front += k;
+        } else {
+            zero_returns++;
+        }
+    }
+    summary[0] = nev;
+    summary[1] = front;
+    summary[2] = zero_returns;
 }
 
 } // extern "C"

@@ -695,3 +695,155 @@ void orc_qpsk_modulate(const uint8_t *symb, size_t len, double *out_real, double
     free(sr);
     free(si);
 }
+
+/* --------------------------------------------------- bit-domain back end
+ *
+ * crc8 (crc/crc8.cpp:6-44, CRC7_POLY 0x91, crc8.h:35), PacketFramer<T>::deserialize
+ * (network/PacketFramer.h:424-513) over a RingBuffer<T> (common/RingBuffer.h), and the receiver's
+ * loop around it (RtlSdr_Receiver/rtlsdr_receiver.cpp:2197-2230), restated literally: the same
+ * passes over the 16 unique-word bits, the same restart at index 1 after a removed bit, the same
+ * early returns (500 bad bits; fewer than a packet's bits left at the end of a pass).  The ring
+ * buffer is modelled as a window [front, front + count) over the caller's bit array (the stream
+ * appended at once); value(i) is only ever read for i < count here, as in the reference. */
+
+static uint8_t orc_crc_table[256];
+static int orc_crc_ready = 0;
+
+static void orc_crc_init(void)
+{
+    for (int i = 0; i < 256; i++) { /* crc8::crc8 + getCRCForByte */
+        uint8_t val = (uint8_t)i;
+        for (int j = 0; j < 8; j++) {
+            if (val & 1) val ^= 0x91;
+            val >>= 1;
+        }
+        orc_crc_table[i] = val;
+    }
+    orc_crc_ready = 1;
+}
+
+uint8_t orc_crc8(const uint8_t *message, size_t length)
+{
+    if (!orc_crc_ready) orc_crc_init();
+    uint8_t crc = 0;
+    for (size_t i = 0; i < length; i++) crc = orc_crc_table[crc ^ message[i]];
+    return crc;
+}
+
+const uint8_t ORC_FRAMER_UW[16] = {1, 1, 1, 1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1, 1, 0}; /* PacketFramer.h:17-19 */
+#define ORC_PKT_BITS 2032 /* MAX_PKT_SIZE_BITS = (250 + 4) * 8 */
+
+typedef struct {
+    const uint8_t *d;
+    size_t front, count;
+} orc_ring;
+
+static uint8_t ring_value(const orc_ring *rb, size_t i) { return i < rb->count ? rb->d[rb->front + i] : 0; }
+static void ring_remove(orc_ring *rb, size_t k)
+{
+    while (k-- && rb->count) { rb->front++; rb->count--; }
+}
+static uint8_t ring_to_byte(const orc_ring *rb, size_t index) /* PacketFramer.h:537-549 */
+{
+    uint8_t c = 0;
+    for (size_t i = 0; i < 8; ++i)
+        if (ring_value(rb, index + i) == 1) c |= (uint8_t)(1 << (7 - i));
+    return c;
+}
+
+/* PacketFramer<T>::deserialize.  Returns 254 (valid packet), 0 or -1 like the reference. */
+static int orc_deserialize(orc_ring *buf, uint8_t *pkt, int crc_enable, int *validPacket, int *validCRC,
+                           int *validHeader, int *bad_bits, uint8_t *len_out, uint8_t *crc_out)
+{
+    *validPacket = 0;
+    *validCRC = 0;
+    *validHeader = 0;
+    *bad_bits = 0;
+    if (buf->count < ORC_PKT_BITS) return 0;
+    do {
+        *validHeader = 1;
+        for (size_t i = 0; i < 16; i++) {
+            if (ring_value(buf, i) != ORC_FRAMER_UW[i]) {
+                (*bad_bits)++;
+                ring_remove(buf, 1);
+                *validHeader = 0;
+                i = 0; /* (sic) the loop's i++ makes the next comparison start at index 1 */
+                if (*bad_bits >= 500) return 0;
+            }
+        }
+        if (buf->count < ORC_PKT_BITS) return 0;
+    } while (!*validHeader);
+    *validHeader = 1;
+    uint8_t pkt_length = ring_to_byte(buf, 16);
+    *len_out = pkt_length;
+    if (pkt_length > 250) {
+        *bad_bits = 1;
+        return -1;
+    }
+    uint8_t pkt_crc = ring_to_byte(buf, 24);
+    *crc_out = pkt_crc;
+    memset(pkt, 0, 250);
+    for (size_t i = 0; i < 250; i++) pkt[i] = ring_to_byte(buf, i * 8 + 32);
+    if (crc_enable) {
+        if (orc_crc8(pkt, pkt_length) == pkt_crc) {
+            *validCRC = 1;
+        } else {
+            *bad_bits = 1;
+            return -1;
+        }
+    } else {
+        *validCRC = 1;
+    }
+    *validPacket = 1;
+    return 254;
+}
+
+/* The receiver's deserializeData loop over a stream of n bits appended at once.
+ * Events (in stream order, at most max_events recorded, all counted): kind 1 = valid packet
+ * (its 250 data bytes go to payload[250 * k]), 2 = length > 250, 3 = CRC mismatch; pos = index of
+ * the header's first bit.  summary = {events, bits consumed (front at exit), calls that returned 0}. */
+void orc_deframe(const uint8_t *bits, size_t n, int crc_enable, size_t max_events, int64_t *ev_pos, int32_t *ev_kind,
+                 uint8_t *ev_len, uint8_t *ev_crc, uint8_t *payload, uint64_t *summary)
+{
+    orc_ring rb = {bits, 0, n};
+    uint8_t pkt[250];
+    uint64_t nev = 0, zero_returns = 0;
+    while (rb.count > ORC_PKT_BITS) {
+        int vp, vc, vh, bad;
+        uint8_t len = 0, crc = 0;
+        int r = orc_deserialize(&rb, pkt, crc_enable, &vp, &vc, &vh, &bad, &len, &crc);
+        if (r > 0 || r == -1) {
+            if (nev < max_events) {
+                ev_pos[nev] = (int64_t)rb.front;
+                ev_kind[nev] = r > 0 ? 1 : (len > 250 ? 2 : 3);
+                ev_len[nev] = len;
+                ev_crc[nev] = (r > 0 || len <= 250) ? crc : 0;
+                if (r > 0) memcpy(payload + 250 * nev, pkt, 250);
+            }
+            nev++;
+            ring_remove(&rb, r > 0 ? (size_t)r * 8 : 1);
+        } else {
+            zero_returns++;
+        }
+    }
+    summary[0] = nev;
+    summary[1] = rb.front;
+    summary[2] = zero_returns;
+}
+
+/* PacketFramer<T>::serialize (PacketFramer.h:363-413): 2032 bits; returns -1 if length > 250 */
+int orc_frame(const uint8_t *data, size_t length, int crc_enable, uint8_t *bits_out)
+{
+    if (length > 250) return -1;
+    memset(bits_out, 0, ORC_PKT_BITS);
+    memcpy(bits_out, ORC_FRAMER_UW, 16);
+    uint8_t crc = crc_enable ? orc_crc8(data, length) : 0;
+    for (int i = 0; i < 8; i++) {
+        bits_out[16 + i] = (uint8_t)((length >> (7 - i)) & 1); /* binary_array[v][i]: MSB first */
+        bits_out[24 + i] = (uint8_t)((crc >> (7 - i)) & 1);
+    }
+    for (size_t i = 0; i < length; i++)
+        for (int j = 0; j < 8; j++) bits_out[32 + i * 8 + j] = (uint8_t)((data[i] >> (7 - j)) & 1);
+    return ORC_PKT_BITS;
+}
+

@@ -136,4 +136,11 @@ void orc_qpsk_modulate(const uint8_t *sym, size_t len, double *out_real, double 
 #ifdef __cplusplus
 }
 #endif
+/* bit-domain back end: crc/crc8.cpp:6-44, network/PacketFramer.h:363-513, common/RingBuffer.h,
+ * RtlSdr_Receiver/rtlsdr_receiver.cpp:2197-2230 */
+uint8_t orc_crc8(const uint8_t *message, size_t length);
+void orc_deframe(const uint8_t *bits, size_t n, int crc_enable, size_t max_events, int64_t *ev_pos, int32_t *ev_kind,
+                 uint8_t *ev_len, uint8_t *ev_crc, uint8_t *payload, uint64_t *summary);
+int orc_frame(const uint8_t *data, size_t length, int crc_enable, uint8_t *bits_out);
+
 #endif

@@ -60,4 +60,28 @@ t = timed(lambda: fm.demod(raw, pcm))
 tot = nchan * nb
 rows.append({"kernel": "rtlfm int16 chain ds=10", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
              "algorithmic_GBps": 2.2 * tot / t / 1e9, "frac_of_8TBps": 2.2 * tot / t / 1e9 / PEAK})
+del raw, pcm
+# bit-domain back end: 1024 channels x 2^18 bits, (a) dense framed packets, (b) noise with no header
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from signals import framed_bit_stream  # noqa: E402
+
+nb = 1 << 18
+one = framed_bit_stream(nb, 1, packet_every=64, p_bad_crc=0.05, p_bad_len=0.05)
+dense = torch.tensor(np.stack([np.roll(one, 37 * c) for c in range(64)]), device=dev).repeat(16, 1).contiguous()
+noise = torch.randint(0, 2, (1024, nb), device=dev, dtype=torch.uint8)
+ev = torch.zeros(1024, 256, 16, dtype=torch.uint8, device=dev)
+pay = torch.zeros(1024, 256, 250, dtype=torch.uint8, device=dev)
+summ = torch.zeros(1024, 4, dtype=torch.int64, device=dev)
+L = _lib.lib()
+import ctypes as C  # noqa: E402
+for name, bits in (("deframe dense packets", dense), ("deframe noise", noise)):
+    def run():
+        _lib.check(L.sdrx_deframe_dev(C.c_void_p(bits.data_ptr()), nb, 1024, nb, 1, C.c_void_p(ev.data_ptr()),
+                                      C.c_void_p(pay.data_ptr()), 256, C.c_void_p(summ.data_ptr()), None))
+    torch.cuda.synchronize()
+    t = timed(run, iters=10, warm=2)
+    tot = 1024 * nb
+    rows.append({"kernel": name + " (1024 ch x 2^18 bits)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
+                 "algorithmic_GBps": 1.0 * tot / t / 1e9, "frac_of_8TBps": 1.0 * tot / t / 1e9 / PEAK,
+                 "events_per_channel": float(summ[:, 0].double().mean().item())})
 print(json.dumps({"peak_GBps": PEAK, "rows": rows}, indent=1))

@@ -31,6 +31,12 @@ class FirJob(C.Structure):
     ]
 
 
+class FrameEvent(C.Structure):
+    """sdrx_frame_event"""
+
+    _fields_ = [("pos", C.c_int64), ("kind", C.c_int32), ("len", C.c_uint8), ("crc", C.c_uint8), ("pad", C.c_uint8 * 2)]
+
+
 class PskState(C.Structure):
     """sdrx_psk_state"""
 
@@ -57,6 +63,7 @@ SIGNATURES = {
     "sdrx_ones_zeros_dev": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "sdrx_fm_demod_dev": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "sdrx_rtlfm_dev": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, C.c_int, _vp, _vp, _vp, _sz, _vp]),
+    "sdrx_deframe_dev": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _sz, _vp, _vp]),
     "sdrx_psk_state_init_bpsk": (None, [C.POINTER(PskState), C.c_uint64, _sz]),
     "sdrx_psk_state_init_qpsk": (None, [C.POINTER(PskState), _vp, _sz]),
     "sdrx_psk_work_bytes": (_sz, [_sz, _sz]),

@@ -163,6 +163,12 @@ extern "C" int sdrx_rtlfm_dev(const uint8_t *iq_u8, size_t n, size_t nchan, size
                         (hipStream_t)stream);
 }
 
+extern "C" int sdrx_deframe_dev(const uint8_t *bits, size_t n, size_t nchan, size_t in_pitch, int crc_enable,
+                                sdrx_frame_event *events, uint8_t *payloads, size_t max_events, uint64_t *summary, void *stream)
+{
+    return launch_deframe(bits, n, nchan, in_pitch, crc_enable, events, payloads, max_events, summary, (hipStream_t)stream);
+}
+
 extern "C" int sdrx_am_demod_dev(const double *re, const double *im, uint8_t *out, size_t n, size_t ds, void *stream)
 {
     return launch_am_demod(re, im, out, n, ds, (hipStream_t)stream);

@@ -148,6 +148,27 @@ class RtlFm:
         return m
 
 
+def deframe(bits, crc_enable=True, max_events=1024):
+    """bits: (nchan, n) uint8 0/1 on the device.  Returns per channel a dict like the reference's loop would leave:
+    events (pos, kind, len, crc as numpy arrays), payload (k, 250), counts; see sdrx_deframe_dev."""
+    assert bits.dtype == torch.uint8 and bits.is_contiguous() and bits.dim() == 2
+    nchan, n = bits.shape
+    ev = torch.zeros(nchan, max_events, 16, dtype=torch.uint8, device=bits.device)
+    pay = torch.zeros(nchan, max_events, 250, dtype=torch.uint8, device=bits.device)
+    summ = torch.zeros(nchan, 4, dtype=torch.int64, device=bits.device)
+    _lib.check(_lib.lib().sdrx_deframe_dev(_ptr(bits), n, nchan, n, int(bool(crc_enable)), _ptr(ev), _ptr(pay), max_events,
+                                           _ptr(summ), _stream()), "sdrx_deframe_dev")
+    summ_h, ev_h, pay_h = summ.cpu().numpy(), ev.cpu().numpy(), pay.cpu().numpy()
+    out = []
+    for c in range(nchan):
+        k = int(min(summ_h[c, 0], max_events))
+        raw = ev_h[c, :k]
+        out.append({"pos": raw[:, :8].copy().view(np.int64).reshape(-1), "kind": raw[:, 8:12].copy().view(np.int32).reshape(-1),
+                    "len": raw[:, 12].copy(), "crc": raw[:, 13].copy(), "payload": pay_h[c, :k],
+                    "events": int(summ_h[c, 0]), "consumed": int(summ_h[c, 1]), "zero_returns": int(summ_h[c, 2])})
+    return out
+
+
 class PskBank:
     """nchan independent BPSK or QPSK demodulators (BPSK.cpp:148-176 / QPSK.cpp:190-219), device resident."""
 

@@ -73,6 +73,14 @@ def lib():
     L.orc_u8_rotate_90.restype = None
     L.orc_u8_to_iq.argtypes = [_u8, _sz, C.c_double, C.c_int, _f64, _f64]
     L.orc_u8_to_iq.restype = None
+    _i64 = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+    _u64 = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+    L.orc_crc8.argtypes = [_u8, _sz]
+    L.orc_crc8.restype = C.c_uint8
+    L.orc_deframe.argtypes = [_u8, _sz, C.c_int, _sz, _i64, _i32, _u8, _u8, _u8, _u64]
+    L.orc_deframe.restype = None
+    L.orc_frame.argtypes = [_u8, _sz, C.c_int, _u8]
+    L.orc_frame.restype = C.c_int
     L.orc_fir_execute_fma.argtypes = [_f64, C.c_int, _f64, _f64, _sz]
     L.orc_fir_execute_fma.restype = None
     L.orc_am_modulate.argtypes = [_u8, _sz, _f64, _sz]
@@ -256,11 +264,55 @@ def ref_available():
     return os.path.exists(REF_LIB)
 
 
+def _deframe_with(fn, bits, crc_enable=True, max_events=4096):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    pos = np.zeros(max_events, dtype=np.int64)
+    kind = np.zeros(max_events, dtype=np.int32)
+    ln = np.zeros(max_events, dtype=np.uint8)
+    crc = np.zeros(max_events, dtype=np.uint8)
+    payload = np.zeros(max_events * 250, dtype=np.uint8)
+    summary = np.zeros(4, dtype=np.uint64)
+    fn(bits, bits.size, int(bool(crc_enable)), max_events, pos, kind, ln, crc, payload, summary)
+    k = int(min(summary[0], max_events))
+    return {"pos": pos[:k], "kind": kind[:k], "len": ln[:k], "crc": crc[:k], "payload": payload.reshape(-1, 250)[:k],
+            "events": int(summary[0]), "consumed": int(summary[1]), "zero_returns": int(summary[2])}
+
+
+def deframe(bits, crc_enable=True, max_events=4096):
+    """receiver loop + PacketFramer::deserialize over a bit stream (oracle restatement)"""
+    return _deframe_with(lib().orc_deframe, bits, crc_enable, max_events)
+
+
+def ref_deframe(bits, crc_enable=True, max_events=4096):
+    """the same through the reference's own PacketFramer / RingBuffer / crc8 (oracle/_ref)"""
+    return _deframe_with(ref().ref_deframe, bits, crc_enable, max_events)
+
+
+def frame(data, crc_enable=True):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.zeros(2032, dtype=np.uint8)
+    r = lib().orc_frame(data, data.size, int(bool(crc_enable)), out)
+    return out if r > 0 else None
+
+
+def crc8(data):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    return int(lib().orc_crc8(data, data.size))
+
+
 def ref():
     global _ref
     if _ref is not None:
         return _ref
     R = C.CDLL(REF_LIB)
+    _i64 = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+    _u64 = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+    R.ref_crc8.argtypes = [_u8, _sz]
+    R.ref_crc8.restype = C.c_uint8
+    R.ref_frame.argtypes = [_u8, _sz, C.c_int, _u8]
+    R.ref_frame.restype = C.c_int
+    R.ref_deframe.argtypes = [_u8, _sz, C.c_int, _sz, _i64, _i32, _u8, _u8, _u8, _u64]
+    R.ref_deframe.restype = None
     R.ref_fir_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
     R.ref_fir_new.restype = C.c_void_p
     R.ref_fir_error.argtypes = [C.c_void_p]

@@ -83,3 +83,31 @@ def psk_test_signal(kind, nsym, seed, phase_deg=0.0, snr_db=None, timing_offset=
     iq = np.empty(2 * n)
     iq[0::2], iq[1::2] = z.real, z.imag
     return iq
+
+
+def framed_bit_stream(n_bits, seed, packet_every=3000, p_bad_crc=0.15, p_bad_len=0.1, p_false_uw=0.002, crc_enable=True):
+    """A bit stream (uint8 0/1) with framed packets (PacketFramer layout: 16-bit unique word, length, crc8,
+    250 data bytes) scattered in noise; some with a corrupted CRC or a length > 250, plus bare unique words."""
+    import _oracle as O
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, n_bits).astype(np.uint8)
+    uw = np.array([1, 1, 1, 1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1, 1, 0], dtype=np.uint8)
+    p = int(rng.integers(0, packet_every))
+    while p + 2032 <= n_bits:
+        ln = int(rng.integers(0, 251))
+        data = rng.integers(0, 256, ln).astype(np.uint8)
+        pkt = O.frame(data, crc_enable).copy()
+        pkt[32 + 8 * ln:] = rng.integers(0, 2, 2032 - 32 - 8 * ln)  # the reference reads all 250 bytes: fill the rest
+        u = rng.random()
+        if u < p_bad_crc:
+            pkt[24 + int(rng.integers(0, 8))] ^= 1
+        elif u < p_bad_crc + p_bad_len:
+            pkt[16:24] = [1, 1, 1, 1, 1, 1, int(rng.integers(0, 2)), 1]  # 253 or 255
+        bits[p:p + 2032] = pkt
+        p += 2032 + int(rng.integers(0, packet_every))
+    for q in np.flatnonzero(rng.random(n_bits // 64) < p_false_uw * 64):
+        q = int(q) * 64 + int(rng.integers(0, 48))
+        if q + 16 <= n_bits:
+            bits[q:q + 16] = uw
+    return bits
+

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import _oracle as O
-from signals import fm_iq, ook_iq, psk_symbols, psk_test_signal, radio_iq
+from signals import fm_iq, framed_bit_stream, ook_iq, psk_symbols, psk_test_signal, radio_iq
 
 pytestmark = pytest.mark.gpu
 
@@ -449,6 +449,62 @@ def test_rtlfm_int16_chain(ds, rot):
         st_dev = fm.state[fm.cur].cpu().numpy()
         for c in range(C_):
             assert np.array_equal(st_dev[c], sts[c]), (c, lo, hi)
+
+
+# =============================================================================== bit-domain back end
+
+@pytest.mark.parametrize("crc_enable", [True, False])
+def test_deframe_vs_oracle(crc_enable):
+    """sdrx_deframe_dev against the oracle's literal restatement of PacketFramer::deserialize + the receiver's
+    loop: 24 channels = 6 random streams (good packets, bad crc, bad length, bare unique words, dense and
+    sparse) cut at 4 lengths each, so that every end-of-stream case (a header exactly one packet before the
+    end, the 500-bit early return, partial passes) is hit: same events, payloads, zero returns and consumed bits."""
+    n = 70000
+    streams, cuts = [], []
+    for seed in range(6):
+        full = framed_bit_stream(n, 500 + seed, packet_every=2500 if seed % 2 else 300, crc_enable=crc_enable)
+        for m in (n, n - 1 - 97 * seed, 2033 + 700 * seed, 40000 + seed):
+            b = np.full(n, 2, dtype=np.uint8)  # beyond a channel's own length: never read
+            b[:m] = full[:m]
+            streams.append(b)
+            cuts.append(m)
+    # channels have different lengths: one launch per distinct length group (n is per launch)
+    for m in sorted(set(cuts)):
+        idx = [i for i, c in enumerate(cuts) if c == m]
+        bits = torch.tensor(np.stack([streams[i][:m] for i in idx]), device="cuda")
+        got = device.deframe(bits, crc_enable, max_events=256)
+        for g, i in zip(got, idx):
+            want = O.deframe(streams[i][:m], crc_enable, max_events=256)
+            for k in ("events", "consumed", "zero_returns"):
+                assert g[k] == want[k], (m, i, k, g[k], want[k])
+            for k in ("pos", "kind", "len", "crc", "payload"):
+                assert np.array_equal(g[k], want[k]), (m, i, k)
+
+
+def test_deframe_edge_lengths_and_golden():
+    """Every stream length around one and two packets (the receiver's loop needs more than 2032 bits; deserialize
+    itself at least 2032), the reference's TEST_PacketFramer stream, streams without any header, and an event
+    buffer that is too small (all events are still counted)."""
+    first64 = [1, 1, 1, 1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+               1, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, 1]
+    gold = np.zeros(5000, dtype=np.uint8)
+    gold[:64] = first64
+    gold[2032:2032 + 64] = first64
+    noise = np.random.default_rng(1).integers(0, 2, 5000).astype(np.uint8)
+    zeros = np.zeros(5000, dtype=np.uint8)
+    for stream in (gold, noise, zeros, framed_bit_stream(5000, 9, packet_every=10)):
+        for m in list(range(2025, 2045)) + list(range(4057, 4072)) + [0, 1, 16, 2531, 2532, 2533, 3100, 5000]:
+            for crc_enable in (False, True):
+                bits = torch.tensor(stream[:m].copy().reshape(1, -1), device="cuda")
+                g = device.deframe(bits, crc_enable, max_events=8)[0]
+                w = O.deframe(stream[:m], crc_enable, max_events=8)
+                assert (g["events"], g["consumed"], g["zero_returns"]) == (w["events"], w["consumed"], w["zero_returns"]), (m, crc_enable)
+                assert np.array_equal(g["pos"], w["pos"]) and np.array_equal(g["kind"], w["kind"]), (m, crc_enable)
+                assert np.array_equal(g["payload"], w["payload"]), (m, crc_enable)
+    dense = framed_bit_stream(60000, 3, packet_every=5, p_bad_crc=0.0, p_bad_len=0.0, p_false_uw=0.0)
+    g = device.deframe(torch.tensor(dense.reshape(1, -1), device="cuda"), True, max_events=4)[0]
+    w = O.deframe(dense, True, max_events=4)
+    assert g["events"] == w["events"] > 4 and g["consumed"] == w["consumed"] and np.array_equal(g["payload"], w["payload"])
 
 
 # =============================================================================== fp32 twins

@@ -359,3 +359,64 @@ def test_fused_fir_variant_is_close_to_the_reference_sum():
         scale = np.convolve(np.abs(x), np.abs(a.taps))[: x.size] + 1e-300
         for lo, hi in ((0, 1234), (1234, 5000)):
             assert np.max(np.abs(a.execute(x[lo:hi]) - b.execute_fma(x[lo:hi])) / scale[lo:hi]) <= 1e-12
+
+
+# ---------------------------------------------------------------- bit-domain back end
+
+FRAMED_MESSAGE_64 = [1, 1, 1, 1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                     1, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, 1]
+
+
+def test_crc_check():
+    """TEST(CRC, crc_check): TEST_crc.cpp:8-17"""
+    assert O.crc8([0x83, 0x01]) == 0x17
+
+
+def test_packetframer_framed_message():
+    """TEST(PacketFramer, FramedMessage): TEST_PacketFramer.cpp:30-54 (crc disabled, 4 data bytes, zeros after)"""
+    bits = O.frame([0x83, 0x01, 0x00, 0xAB], crc_enable=False)
+    assert bits.size == (250 + 4) * 8
+    assert list(bits[:64]) == FRAMED_MESSAGE_64 and not bits[64:80].any()
+
+
+def _feed_one_by_one(first64, crc_enable):
+    """The reference tests append one bit at a time to a ring buffer of exactly one packet and call
+    deserialize after each: only the call on the full buffer (2032 bits) can return non-zero.  The batch
+    form equals that last call once one more bit has arrived (the receiver's loop wants count > 2032)."""
+    stream = np.zeros(2033, dtype=np.uint8)
+    stream[:64] = first64
+    for n in (1, 64, 1000, 2032):  # not enough bits: nothing happens, nothing is consumed
+        r = O.deframe(stream[:n], crc_enable)
+        assert r["events"] == 0 and r["consumed"] == 0
+    return O.deframe(stream, crc_enable)
+
+
+def test_packetframer_good_deframed_packet():
+    """TEST(PacketFramer, GoodDeframedPacket): TEST_PacketFramer.cpp:57-125"""
+    r = _feed_one_by_one(FRAMED_MESSAGE_64, crc_enable=False)
+    assert r["events"] == 1 and r["kind"][0] == 1 and r["pos"][0] == 0 and r["len"][0] == 4
+    assert list(r["payload"][0][:4]) == [0x83, 0x01, 0x00, 0xAB] and not r["payload"][0][4:].any()
+    assert r["consumed"] == 2032
+
+
+def test_packetframer_bad_crc():
+    """TEST(PacketFramer, BadCRC): TEST_PacketFramer.cpp:128-195 -- return -1, header valid, one bad bit"""
+    r = _feed_one_by_one(FRAMED_MESSAGE_64, crc_enable=True)
+    assert r["events"] >= 1 and r["kind"][0] == 3 and r["pos"][0] == 0
+
+
+def test_packetframer_bad_header():
+    """TEST(PacketFramer, BadHeader): TEST_PacketFramer.cpp:198-265 -- no header: returns 0 after 500 removed bits"""
+    bad = list(FRAMED_MESSAGE_64)
+    bad[0] = bad[1] = 0
+    r = _feed_one_by_one(bad, crc_enable=True)
+    assert r["events"] == 0 and r["zero_returns"] == 1 and r["consumed"] == 500
+
+
+def test_packetframer_bad_length():
+    """TEST(PacketFramer, BadLength): TEST_PacketFramer.cpp:268-335 -- length 255 > 250: return -1"""
+    bad = list(FRAMED_MESSAGE_64)
+    bad[16:24] = [1] * 8
+    r = _feed_one_by_one(bad, crc_enable=False)
+    assert r["events"] >= 1 and r["kind"][0] == 2 and r["pos"][0] == 0 and r["len"][0] == 255
+

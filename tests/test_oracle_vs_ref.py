@@ -155,3 +155,37 @@ def test_resample_helpers_match_reference():
         a, b = x.copy(), x.copy()
         assert R.ref_decimate(a, n, by) == L.orc_decimate(b, n, by)
         assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------- crc8 / PacketFramer / RingBuffer
+
+def test_crc8_and_frame_vs_reference():
+    rng = np.random.default_rng(4)
+    R = O.ref()
+    for ln in (0, 1, 2, 17, 249, 250):
+        data = rng.integers(0, 256, max(ln, 1)).astype(np.uint8)[:ln]
+        d = np.ascontiguousarray(data if ln else np.zeros(1, dtype=np.uint8))
+        assert O.lib().orc_crc8(d, ln) == R.ref_crc8(d, ln)
+        for crc_enable in (0, 1):
+            a, b = np.zeros(2032, dtype=np.uint8), np.zeros(2032, dtype=np.uint8)
+            assert O.lib().orc_frame(d, ln, crc_enable, a) == R.ref_frame(d, ln, crc_enable, b) == 2032
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("crc_enable", [True, False])
+def test_deframe_vs_reference(seed, crc_enable):
+    """The literal restatement of deserialize + the receiver's loop against the reference's own PacketFramer /
+    RingBuffer / crc8 on random streams with good packets, bad CRCs, bad lengths and bare unique words:
+    same events, same payloads, same number of zero returns, same bits consumed -- for several stream
+    lengths, so that the end-of-stream behaviour (partial passes, the 500-bit early return) is exercised."""
+    from signals import framed_bit_stream
+    full = framed_bit_stream(60000, 100 + seed, packet_every=2500 if seed % 2 else 400, crc_enable=crc_enable)
+    for n in (60000, 59999, 50011, 31000, 2033, 2032, 2600, 4063, 4064, 4065, 4600):
+        a, b = O.deframe(full[:n], crc_enable), O.ref_deframe(full[:n], crc_enable)
+        for k in ("events", "consumed", "zero_returns"):
+            assert a[k] == b[k], (n, k, a[k], b[k])
+        for k in ("pos", "kind", "len", "crc", "payload"):
+            assert np.array_equal(a[k], b[k]), (n, k)
+    assert O.deframe(full, crc_enable)["events"] > 5
+
