@@ -1,6 +1,7 @@
 /*
  * sdrx.h -- C ABI of libsdrx.so: the MI355X (gfx950) implementation of RadioNode's
- * baseband DSP hot path (FIR Filter + AM / FM / BPSK / QPSK modulators, demodulators).
+ * baseband DSP hot path (FIR Filter + AM / FM / BPSK / QPSK modulators, demodulators), and of
+ * the steps on either side of it (raw-byte ingest in front, packet deframing behind).
  *
  * Plain pointers and sizes only; no C++ or torch types.  Three layers:
  *   1. device layer  (sdrx_*_dev)  : device pointers + a hipStream_t (void*), asynchronous,
@@ -12,10 +13,11 @@
  *   3. legacy layer  (am_gpu_*, fm_gpu_*, ones_zeros_demodulation) : the reference's own
  *                                    extern "C" GPU entry points, byte-for-byte signatures.
  *
- * Every entry point cites the reference interface it replaces.  All arithmetic is IEEE fp64
- * with the reference's operation order and no FMA contraction, so filtered samples, bits and
- * symbol decisions are bit-identical to RadioNode's CPU path (see DESIGN.md for the two
- * transcendental exceptions: device sincos/atan2 are include/sdrx_math.h).
+ * Every entry point cites the reference interface it replaces.  By default all arithmetic is
+ * IEEE fp64 with the reference's operation order and no FMA contraction, so filtered samples,
+ * bits and symbol decisions are bit-identical to RadioNode's CPU path (see DESIGN.md for the two
+ * transcendental exceptions: device sincos/atan2 are include/sdrx_math.h).  Opt-in variants
+ * (sdrx_fir_job.fast_fma, .dtype = SDRX_F32) trade that for speed within stated tolerances.
  *
  * Return convention for new symbols: 0 = SDRX_OK, negative = error (sdrx_last_error()).
  */
@@ -35,11 +37,11 @@ extern "C" {
 #define SDRX_EUNSUPPORTED (-3) /* shape outside the kernels' limits */
 #define SDRX_ENOMEM (-4)
 
-/* sample layouts at the device boundary */
 /* sample type of a device-layer FIR job */
 #define SDRX_F64 0
 #define SDRX_F32 1
 
+/* sample layouts at the device boundary */
 #define SDRX_REAL 0           /* one rail: in0 = T[n] */
 #define SDRX_IQ_SPLIT 1       /* in0 = re[n], in1 = im[n]  (AM.h:63, FM.h:112, rtlsdr_receiver.cpp:1994-1995) */
 #define SDRX_IQ_INTERLEAVED 2 /* in0 = {re,im}[n] = std::complex<double>[n] (Common_Deffinitions.h:12-13, BBP_Block.h:14) */
