@@ -147,6 +147,35 @@ typedef struct sdrx_frame_event {
 int sdrx_deframe_dev(const uint8_t *bits, size_t n, size_t nchan, size_t in_pitch, int crc_enable, sdrx_frame_event *events,
                      uint8_t *payloads, size_t max_events, uint64_t *summary, void *stream);
 
+/* The reference's DigitalSignalProcessing primitives on `nchan` rows of n doubles (row c at c * pitch), in place or
+ * x -> y; every row is computed in the reference's operation order (bit-identical to the CPU classes).
+ *   SDRX_IIR_DC_BLOCK   DC_Filter::update (DC_Filter.cpp:12-19), coef = {R}; restarts at every call like the reference
+ *   SDRX_IIR_LOWPASS    LowPassFilter::update per sample (LowPassFilter.cpp:13-16), coef = {ePow = sdrx_lowpass1_coef()},
+ *                       state[4c] = `output`
+ *   SDRX_IIR_NOTCH      NotchFilter::filter (NotchFilter.cpp:18-37), coef = sdrx_notch_design(); state[4c..4c+3] =
+ *                       x_1, x_2, y_1, y_2 (function statics in the reference, per channel here); the first two samples
+ *                       of every call pass through and do not enter the delay line
+ *   SDRX_IIR_INTEGRATE  FirstOrderDigitalIntegration::integrate (:12-18), coef = {tStep = 1.0f / sampleRate}; restarts
+ * coef is host memory; state is device memory, nchan x 4 doubles, read and written (NULL = zeros, not kept). */
+enum { SDRX_IIR_DC_BLOCK = 0, SDRX_IIR_LOWPASS = 1, SDRX_IIR_NOTCH = 2, SDRX_IIR_INTEGRATE = 3 };
+int sdrx_iir_dev(int kind, const double *coef, const double *x, double *y, size_t n, size_t nchan, size_t pitch,
+                 double *state, void *stream);
+double sdrx_lowpass1_coef(double cutoff_frequency, double delta_time);          /* LowPassFilter.cpp:7-11 */
+void sdrx_notch_design(double notch_bw, double center_freq, double *coef5);      /* NotchFilter.cpp:7-16: a0 a1 a2 b1 b2 */
+/* normalize (Normalize.cpp:7-22; the BBP_Block overload :24-43 is the same over the 2n doubles of the points):
+ * max_inout[c] holds prev_max on entry and the returned maximum (an integer value: the reference keeps it in a size_t)
+ * on exit; x = (x / max) * 2 - 1. */
+int sdrx_normalize_dev(double *x, size_t n, size_t nchan, size_t pitch, double *max_inout, void *stream);
+/* fifth_order_filter::decimate(double*, size_t, size_t) (fifth_order_filter.cpp:65-88), in place, log2(decimate_by)
+ * passes over the same n like the reference; state6[6c..] = r_a..r_f carried (zeros for a new filter).  The reference
+ * returns n / decimate_by; samples beyond the last written one keep their values. */
+int sdrx_fifth_order_decimate_dev(double *data, size_t n, size_t nchan, size_t pitch, size_t decimate_by, double *state6,
+                                  void *stream);
+/* fft (FFT.cpp:7-28): in-place radix-2 transforms of nchan rows of n complex doubles (pitch in complex elements),
+ * n a power of two <= SDRX_FFT_MAX; twiddles from sdrx_math.h's sincos (<= 1e-12 of the libm build). */
+#define SDRX_FFT_MAX 4096
+int sdrx_fft_dev(double *iq, size_t n, size_t nchan, size_t pitch, void *stream);
+
 /* PSK loop state of one channel: the reference's public loop structs (BPSK.h:130-276) flattened. */
 typedef struct sdrx_psk_state {
     double nco_delay, reg_mu, reg_Q, reg_I, mu_delay; /* NcoControlVariables.delay, Register_*, muDelay */

@@ -20,6 +20,13 @@
 #include <common/RingBuffer.h>
 #include <crc/crc8.h>
 #include <network/PacketFramer.h>
+#include <DigitalSignalProcessing/DC_Filter.h>
+#include <DigitalSignalProcessing/LowPassFilter.h>
+#include <DigitalSignalProcessing/NotchFilter.h>
+#include <DigitalSignalProcessing/FirstOrderDigitalIntegration.h>
+#include <DigitalSignalProcessing/Normalize.h>
+#include <DigitalSignalProcessing/fifth_order_filter.h>
+#include <DigitalSignalProcessing/FFT.h>
 
 extern "C" {
 
@@ -239,6 +246,29 @@ void ref_deframe(const uint8_t *bits, size_t n, int crc_enable, size_t max_event
     summary[0] = nev;
     summary[1] = front;
     summary[2] = zero_returns;
+}
+
+// ---- DigitalSignalProcessing primitives ----
+void ref_dc_block(double *in, double *out, size_t n, double R) { DC_Filter f(R); f.update(in, out, n); }
+void *ref_lowpass1_new(double cutoff, double dt) { return new LowPassFilter(cutoff, dt); }
+void ref_lowpass1_free(void *h) { delete (LowPassFilter *)h; }
+void ref_lowpass1(void *h, const double *in, double *out, size_t n)
+{
+    for (size_t i = 0; i < n; i++) out[i] = ((LowPassFilter *)h)->update(in[i]);
+}
+// The delay line of NotchFilter::filter is function-static: one per process, never reset.
+void ref_notch(double notch_bw, double center_freq, double *block, size_t n) { NotchFilter f(notch_bw, center_freq); f.filter(block, n); }
+void ref_integrate(double sample_rate, double *a, size_t n) { FirstOrderDigitalIntegration f(sample_rate); f.integrate(a, n); }
+double ref_normalize(double *block, size_t n, double prev_max) { return normalize(block, n, prev_max); }
+void *ref_fifth_new() { return new fifth_order_filter(); }
+void ref_fifth_free(void *h) { delete (fifth_order_filter *)h; }
+size_t ref_fifth_decimate(void *h, double *data, size_t n, size_t by) { return ((fifth_order_filter *)h)->decimate(data, n, by); }
+void ref_fft(double *iq, size_t n)
+{
+    Complex_Array a(n);
+    for (size_t i = 0; i < n; i++) a[i] = Complex(iq[2 * i], iq[2 * i + 1]);
+    fft(a, n);
+    for (size_t i = 0; i < n; i++) iq[2 * i] = a[i].real(), iq[2 * i + 1] = a[i].imag();
 }
 
 } // extern "C"

@@ -847,3 +847,127 @@ int orc_frame(const uint8_t *data, size_t length, int crc_enable, uint8_t *bits_
     return ORC_PKT_BITS;
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * DSP primitives.  None of them has a caller or a test in the reference;
+ * the restatements are pinned, in the build container, to the reference's own files compiled
+ * into oracle/_ref (tests/test_oracle_vs_ref.py).
+ * ------------------------------------------------------------------------------------------ */
+
+/* DC_Filter::update (DC_Filter.cpp:12-19): y(n) = x(n) - x(n-1) + R*y(n-1), y(0) = x(0); no carried state */
+void orc_dc_block(const double *in, double *out, size_t n, double R)
+{
+    if (n == 0) return;
+    out[0] = in[0];
+    for (size_t i = 1; i < n; i++) out[i] = in[i] - in[i - 1] + R * out[i - 1];
+}
+
+double orc_lowpass1_coef(double cutoff, double dt) { return 1.0 - exp(-dt * cutoff); }
+
+/* LowPassFilter::update (LowPassFilter.cpp:13-16) called once per sample; *state1 = `output` */
+void orc_lowpass1(const double *in, double *out, size_t n, double ePow, double *state1)
+{
+    double o = *state1;
+    for (size_t i = 0; i < n; i++) {
+        o += (in[i] - o) * ePow;
+        out[i] = o;
+    }
+    *state1 = o;
+}
+
+/* NotchFilter::NotchFilter (NotchFilter.cpp:7-16) */
+void orc_notch_design(double notch_bw, double center_freq, double *coef5)
+{
+    double R = 1.0 * notch_bw;
+    double K = (1 - 2 * R * cos(2.0 * 3.14159 * center_freq) + R * R) / (2 - 2 * cos(2 * 3.14159 * center_freq));
+    coef5[0] = K;
+    coef5[1] = -2.0 * K * cos(2.0 * 3.14159 * center_freq);
+    coef5[2] = K;
+    coef5[3] = 2.0 * R * cos(2.0 * 3.14159 * center_freq);
+    coef5[4] = -(R * R);
+}
+
+/* NotchFilter::filter (NotchFilter.cpp:18-37): in place from index 2 (the first two samples of
+ * every block neither change nor enter the delay line); the delays are function statics in the
+ * reference (shared by all instances), per-channel state here. */
+void orc_notch(double *b, size_t n, const double *c, double *st)
+{
+    double x_1 = st[0], x_2 = st[1], y_1 = st[2], y_2 = st[3];
+    for (size_t i = 2; i < n; i++) {
+        double delay = b[i];
+        b[i] = c[0] * b[i] + c[1] * x_1 + c[2] * x_2 + c[3] * y_1 + c[4] * y_2;
+        x_2 = x_1;
+        x_1 = delay;
+        y_2 = y_1;
+        y_1 = b[i];
+    }
+    st[0] = x_1, st[1] = x_2, st[2] = y_1, st[3] = y_2;
+}
+
+/* FirstOrderDigitalIntegration::integrate (FirstOrderDigitalIntegration.cpp:12-18); tStep = 1.0f/sampleRate */
+void orc_integrate(double *a, size_t n, double tStep)
+{
+    for (size_t i = 1; i < n; i++) a[i] = a[i - 1] + tStep * a[i];
+}
+
+/* normalize (Normalize.cpp:7-22): the running maximum is a size_t (truncated on every update);
+ * abs() resolves to the double overload with libstdc++'s <cmath>/<stdlib.h>.  The BBP_Block
+ * overload (:24-43) is the same loop over the 2n doubles of the complex points. */
+double orc_normalize(double *block, size_t n, double prev_max)
+{
+    size_t max = (size_t)prev_max;
+    for (size_t i = 0; i < n; i++)
+        if ((double)max < fabs(block[i])) max = (size_t)fabs(block[i]);
+    for (size_t i = 0; i < n; i++) block[i] = (block[i] / (double)max) * 2.0 - 1.0;
+    return (double)max;
+}
+
+/* fifth_order_filter::decimate(double*, size_t, size_t) (fifth_order_filter.cpp:65-88), a=1 b=5 c=10 d=11 */
+size_t orc_fifth_order_decimate(double *data, size_t n, size_t decimate_by, double *s)
+{
+    const double a = 1, b = 5, c = 10, d = 11;
+    double r_a = s[0], r_b = s[1], r_c = s[2], r_d = s[3], r_e = s[4], r_f = s[5];
+    if (n == 0) return 0; /* the reference writes data[0] even then */
+    for (size_t dec = 2; dec <= decimate_by; dec *= 2) {
+        data[0] = ((a * (r_a + r_f)) + ((r_b + r_e) * b) + ((r_c + r_d) * c)) / d;
+        for (size_t i = 2; i < n; i += 2) {
+            r_a = r_c;
+            r_b = r_d;
+            r_c = r_e;
+            r_d = r_f;
+            r_e = data[i - 2];
+            r_f = data[i];
+            data[i / 2] = ((a * (r_a + r_f)) + ((r_b + r_e) * b) + ((r_c + r_d) * c)) / d;
+        }
+    }
+    s[0] = r_a, s[1] = r_b, s[2] = r_c, s[3] = r_d, s[4] = r_e, s[5] = r_f;
+    return n / decimate_by;
+}
+
+/* fft (FFT.cpp:7-28): recursive radix-2 decimation in time on std::complex<double>;
+ * twiddle = std::polar(1.0, -2*PI*k/N) = (cos, sin); complex product = (ac-bd, ad+bc). */
+static void fft_rec(double *x, size_t N, int math_mode)
+{
+    if (N <= 1) return;
+    size_t h = N / 2;
+    double *even = (double *)malloc(sizeof(double) * 2 * h), *odd = (double *)malloc(sizeof(double) * 2 * h);
+    for (size_t k = 0; k < h; k++) {
+        even[2 * k] = x[4 * k], even[2 * k + 1] = x[4 * k + 1];
+        odd[2 * k] = x[4 * k + 2], odd[2 * k + 1] = x[4 * k + 3];
+    }
+    fft_rec(even, h, math_mode);
+    fft_rec(odd, h, math_mode);
+    for (size_t k = 0; k < h; k++) {
+        double theta = -2 * 3.141592653589793238460 * (double)k / (double)N, wr, wi;
+        if (math_mode == ORC_MATH_SHARED) sdrx_sincos(theta, &wi, &wr);
+        else wr = cos(theta), wi = sin(theta);
+        wr = 1.0 * wr, wi = 1.0 * wi;
+        double tr = wr * odd[2 * k] - wi * odd[2 * k + 1], ti = wr * odd[2 * k + 1] + wi * odd[2 * k];
+        x[2 * k] = even[2 * k] + tr, x[2 * k + 1] = even[2 * k + 1] + ti;
+        x[2 * (k + h)] = even[2 * k] - tr, x[2 * (k + h) + 1] = even[2 * k + 1] - ti;
+    }
+    free(even);
+    free(odd);
+}
+
+void orc_fft(double *iq, size_t n, int math_mode) { fft_rec(iq, n, math_mode); }

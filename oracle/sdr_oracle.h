@@ -22,6 +22,18 @@
 
 #ifdef __cplusplus
 extern "C" {
+/* DSP primitives: DigitalSignalProcessing/{DC_Filter,LowPassFilter,NotchFilter,
+ * FirstOrderDigitalIntegration,Normalize,fifth_order_filter,FFT}.cpp */
+void orc_dc_block(const double *in, double *out, size_t n, double R);            /* DC_Filter.cpp:12-19 */
+double orc_lowpass1_coef(double cutoff, double dt);                              /* LowPassFilter.cpp:7-11 */
+void orc_lowpass1(const double *in, double *out, size_t n, double ePow, double *state1); /* LowPassFilter.cpp:13-16, per sample */
+void orc_notch_design(double notch_bw, double center_freq, double *coef5);       /* NotchFilter.cpp:7-16: a0,a1,a2,b1,b2 */
+void orc_notch(double *block, size_t n, const double *coef5, double *state4);    /* NotchFilter.cpp:18-37; state = x_1,x_2,y_1,y_2 */
+void orc_integrate(double *array, size_t n, double tStep);                       /* FirstOrderDigitalIntegration.cpp:12-18 */
+double orc_normalize(double *block, size_t n, double prev_max);                  /* Normalize.cpp:7-22 */
+size_t orc_fifth_order_decimate(double *data, size_t n, size_t decimate_by, double *state6); /* fifth_order_filter.cpp:65-88; state = r_a..r_f */
+void orc_fft(double *iq, size_t n, int math_mode);                               /* FFT.cpp:7-28, n a power of two, interleaved complex */
+
 #endif
 
 /* math_mode for the transcendental calls inside loops */
@@ -135,6 +147,18 @@ void orc_qpsk_modulate(const uint8_t *sym, size_t len, double *out_real, double 
 
 #ifdef __cplusplus
 }
+/* DSP primitives: DigitalSignalProcessing/{DC_Filter,LowPassFilter,NotchFilter,
+ * FirstOrderDigitalIntegration,Normalize,fifth_order_filter,FFT}.cpp */
+void orc_dc_block(const double *in, double *out, size_t n, double R);            /* DC_Filter.cpp:12-19 */
+double orc_lowpass1_coef(double cutoff, double dt);                              /* LowPassFilter.cpp:7-11 */
+void orc_lowpass1(const double *in, double *out, size_t n, double ePow, double *state1); /* LowPassFilter.cpp:13-16, per sample */
+void orc_notch_design(double notch_bw, double center_freq, double *coef5);       /* NotchFilter.cpp:7-16: a0,a1,a2,b1,b2 */
+void orc_notch(double *block, size_t n, const double *coef5, double *state4);    /* NotchFilter.cpp:18-37; state = x_1,x_2,y_1,y_2 */
+void orc_integrate(double *array, size_t n, double tStep);                       /* FirstOrderDigitalIntegration.cpp:12-18 */
+double orc_normalize(double *block, size_t n, double prev_max);                  /* Normalize.cpp:7-22 */
+size_t orc_fifth_order_decimate(double *data, size_t n, size_t decimate_by, double *state6); /* fifth_order_filter.cpp:65-88; state = r_a..r_f */
+void orc_fft(double *iq, size_t n, int math_mode);                               /* FFT.cpp:7-28, n a power of two, interleaved complex */
+
 #endif
 /* bit-domain back end: crc/crc8.cpp:6-44, network/PacketFramer.h:363-513, common/RingBuffer.h,
  * RtlSdr_Receiver/rtlsdr_receiver.cpp:2197-2230 */
@@ -142,5 +166,29 @@ uint8_t orc_crc8(const uint8_t *message, size_t length);
 void orc_deframe(const uint8_t *bits, size_t n, int crc_enable, size_t max_events, int64_t *ev_pos, int32_t *ev_kind,
                  uint8_t *ev_len, uint8_t *ev_crc, uint8_t *payload, uint64_t *summary);
 int orc_frame(const uint8_t *data, size_t length, int crc_enable, uint8_t *bits_out);
+
+/* DSP primitives: DigitalSignalProcessing/{DC_Filter,LowPassFilter,NotchFilter,
+ * FirstOrderDigitalIntegration,Normalize,fifth_order_filter,FFT}.cpp */
+void orc_dc_block(const double *in, double *out, size_t n, double R);            /* DC_Filter.cpp:12-19 */
+double orc_lowpass1_coef(double cutoff, double dt);                              /* LowPassFilter.cpp:7-11 */
+void orc_lowpass1(const double *in, double *out, size_t n, double ePow, double *state1); /* LowPassFilter.cpp:13-16, per sample */
+void orc_notch_design(double notch_bw, double center_freq, double *coef5);       /* NotchFilter.cpp:7-16: a0,a1,a2,b1,b2 */
+void orc_notch(double *block, size_t n, const double *coef5, double *state4);    /* NotchFilter.cpp:18-37; state = x_1,x_2,y_1,y_2 */
+void orc_integrate(double *array, size_t n, double tStep);                       /* FirstOrderDigitalIntegration.cpp:12-18 */
+double orc_normalize(double *block, size_t n, double prev_max);                  /* Normalize.cpp:7-22 */
+size_t orc_fifth_order_decimate(double *data, size_t n, size_t decimate_by, double *state6); /* fifth_order_filter.cpp:65-88; state = r_a..r_f */
+void orc_fft(double *iq, size_t n, int math_mode);                               /* FFT.cpp:7-28, n a power of two, interleaved complex */
+
+/* DSP primitives: DigitalSignalProcessing/{DC_Filter,LowPassFilter,NotchFilter,
+ * FirstOrderDigitalIntegration,Normalize,fifth_order_filter,FFT}.cpp */
+void orc_dc_block(const double *in, double *out, size_t n, double R);            /* DC_Filter.cpp:12-19 */
+double orc_lowpass1_coef(double cutoff, double dt);                              /* LowPassFilter.cpp:7-11 */
+void orc_lowpass1(const double *in, double *out, size_t n, double ePow, double *state1); /* LowPassFilter.cpp:13-16, per sample */
+void orc_notch_design(double notch_bw, double center_freq, double *coef5);       /* NotchFilter.cpp:7-16: a0,a1,a2,b1,b2 */
+void orc_notch(double *block, size_t n, const double *coef5, double *state4);    /* NotchFilter.cpp:18-37; state = x_1,x_2,y_1,y_2 */
+void orc_integrate(double *array, size_t n, double tStep);                       /* FirstOrderDigitalIntegration.cpp:12-18 */
+double orc_normalize(double *block, size_t n, double prev_max);                  /* Normalize.cpp:7-22 */
+size_t orc_fifth_order_decimate(double *data, size_t n, size_t decimate_by, double *state6); /* fifth_order_filter.cpp:65-88; state = r_a..r_f */
+void orc_fft(double *iq, size_t n, int math_mode);                               /* FFT.cpp:7-28, n a power of two, interleaved complex */
 
 #endif

@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from sdr_amd import _lib, device  # noqa: E402
 
 device.init(0)
+torch.manual_seed(0)
 dev = torch.device("cuda", 0)
 PEAK = 8000.0
 
@@ -84,4 +85,31 @@ for name, bits in (("deframe dense packets", dense), ("deframe noise", noise)):
     rows.append({"kernel": name + " (1024 ch x 2^18 bits)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
                  "algorithmic_GBps": 1.0 * tot / t / 1e9, "frac_of_8TBps": 1.0 * tot / t / 1e9 / PEAK,
                  "events_per_channel": float(summ[:, 0].double().mean().item())})
+del dense, noise, ev, pay, summ
+# DSP primitives: 16384 rows x 2^13 doubles (1 GiB), read + write = 16 B per sample
+nchan, n = 16384, 1 << 13
+x = torch.randn(nchan, n, dtype=torch.float64, device=dev) * 50
+st = torch.zeros(nchan, 4, dtype=torch.float64, device=dev)
+mx = torch.zeros(nchan, dtype=torch.float64, device=dev)
+st6 = torch.zeros(nchan, 6, dtype=torch.float64, device=dev)
+z = torch.randn(nchan * 2, n // 4, dtype=torch.complex128, device=dev)  # 32768 transforms of 2048 points
+coef = device.notch_design(0.9, 0.05)
+
+
+def _norm():
+    mx.zero_()
+    device.normalize(x, mx)
+
+
+for name, fn, bytes_per in (("iir dc_block", lambda: device.iir(device.IIR_DC_BLOCK, 0.995, x), 16.0),
+                            ("iir lowpass1", lambda: device.iir(device.IIR_LOWPASS, 0.06, x, state=st), 16.0),
+                            ("iir notch", lambda: device.iir(device.IIR_NOTCH, coef, x, state=st), 16.0),
+                            ("iir integrate", lambda: device.iir(device.IIR_INTEGRATE, 1e-9, x), 16.0),
+                            ("normalize (max pass + scale pass)", _norm, 24.0),
+                            ("fifth_order decimate by 2", lambda: device.fifth_order_decimate(x, 2, st6), 4.0 + 4.0),
+                            ("fft 2048 points x 32768", lambda: device.fft(z), 16.0)):
+    t = timed(fn, iters=10, warm=2)
+    tot = nchan * n
+    rows.append({"kernel": name + " (16384 rows x 2^13)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
+                 "algorithmic_GBps": bytes_per * tot / t / 1e9, "frac_of_8TBps": bytes_per * tot / t / 1e9 / PEAK})
 print(json.dumps({"peak_GBps": PEAK, "rows": rows}, indent=1))

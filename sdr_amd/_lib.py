@@ -64,6 +64,12 @@ SIGNATURES = {
     "sdrx_fm_demod_dev": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "sdrx_rtlfm_dev": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, C.c_int, _vp, _vp, _vp, _sz, _vp]),
     "sdrx_deframe_dev": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _sz, _vp, _vp]),
+    "sdrx_iir_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
+    "sdrx_lowpass1_coef": (C.c_double, [C.c_double, C.c_double]),
+    "sdrx_notch_design": (None, [C.c_double, C.c_double, _vp]),
+    "sdrx_normalize_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp, _vp]),
+    "sdrx_fifth_order_decimate_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, _vp]),
+    "sdrx_fft_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp]),
     "sdrx_psk_state_init_bpsk": (None, [C.POINTER(PskState), C.c_uint64, _sz]),
     "sdrx_psk_state_init_qpsk": (None, [C.POINTER(PskState), _vp, _sz]),
     "sdrx_psk_work_bytes": (_sz, [_sz, _sz]),

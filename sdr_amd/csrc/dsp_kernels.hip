@@ -1,0 +1,474 @@
+// dsp_kernels.hip -- the reference's DigitalSignalProcessing primitives as batched kernels
+// (SURVEY section 8f rank 3).  Reference: RadioNode/src/libraries/DigitalSignalProcessing/
+//   DC_Filter.cpp:12-19, LowPassFilter.cpp:7-16, NotchFilter.cpp:7-37,
+//   FirstOrderDigitalIntegration.cpp:12-18, Normalize.cpp:7-43, fifth_order_filter.cpp:65-88, FFT.cpp:7-28.
+// None of them has a caller in the reference; they are here so that a bank of channels can run
+// them where the samples already are.  Same contract as the rest of the library: inside one
+// channel every operation happens in the reference's order with one rounding each
+// (-ffp-contract=off); parallelism is across channels (the recurrences), across outputs
+// (normalize, the fifth-order decimator) or across butterflies of one stage (fft).
+#include "sdrx_internal.h"
+
+#include <cstdlib>
+#include <mutex>
+
+#include "../../include/sdrx_math.h"
+
+namespace sdrx {
+namespace {
+
+struct IirCoef {
+    double c[5];
+};
+
+enum { K_DC = SDRX_IIR_DC_BLOCK, K_LP = SDRX_IIR_LOWPASS, K_NOTCH = SDRX_IIR_NOTCH, K_INT = SDRX_IIR_INTEGRATE };
+
+// samples that need their index looked at before the recurrence is in its steady form
+template <int KIND> constexpr int iir_prologue() { return KIND == K_NOTCH ? 2 : (KIND == K_LP ? 0 : 1); }
+
+template <int KIND> __device__ __forceinline__ double iir_first(double x, double (&s)[4])
+{
+    // DC_Filter: output[0] = input[0]; integrate: array[0] stays; notch: samples 0 and 1 stay
+    // and do not enter the delay line.
+    if (KIND == K_DC) s[0] = x, s[1] = x;
+    if (KIND == K_INT) s[0] = x;
+    return x;
+}
+
+template <int KIND> __device__ __forceinline__ double iir_step(double x, double (&s)[4], const IirCoef &k)
+{
+    if (KIND == K_DC) { // y(n) = x(n) - x(n-1) + R*y(n-1)
+        double y = x - s[0] + k.c[0] * s[1];
+        s[0] = x, s[1] = y;
+        return y;
+    }
+    if (KIND == K_LP) { // output += (input - output) * ePow
+        s[0] += (x - s[0]) * k.c[0];
+        return s[0];
+    }
+    if (KIND == K_NOTCH) { // s = x_1, x_2, y_1, y_2
+        double y = k.c[0] * x + k.c[1] * s[0] + k.c[2] * s[1] + k.c[3] * s[2] + k.c[4] * s[3];
+        s[1] = s[0], s[0] = x, s[3] = s[2], s[2] = y;
+        return y;
+    }
+    double y = s[0] + k.c[0] * x; // array[i] = array[i-1] + tStep*array[i]
+    s[0] = y;
+    return y;
+}
+
+// One channel per lane: the recurrences are serial in time.  A wave owns 64 rows and walks them in
+// chunks of 16 samples (one 128-byte line per row).  Global accesses are row-coalesced -- an
+// instruction covers 4 rows x 16 consecutive samples -- and a wave-private LDS tile (pitch 17: the
+// per-lane reads are conflict-free) turns them into each lane's own run; the next chunk's loads are
+// in flight while the current one is computed.  No s_barrier: nothing is shared between waves.
+constexpr int IC = 16, IPITCH = IC + 1;
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int KIND, bool GUARD>
+__device__ __forceinline__ void iir_chunk(double (&v)[IC], double (&s)[4], const IirCoef &k, size_t s0, size_t n)
+{
+    constexpr int P = iir_prologue<KIND>();
+#pragma unroll
+    for (int j = 0; j < IC; j++) {
+        if (GUARD && s0 + j >= n) break;
+        if (j < P && s0 == 0) v[j] = iir_first<KIND>(v[j], s);
+        else v[j] = iir_step<KIND>(v[j], s, k);
+    }
+}
+
+// CW = rows per wave (64, 16 or 4).  The chain of one row is latency-bound (2-5 dependent fp64 operations
+// per sample), so a bank with few rows is spread over more waves: with CW < 64 the lanes l and l + CW
+// compute the same row redundantly and only the first copy writes.
+template <int KIND, int CW>
+__global__ __launch_bounds__(64) void iir_kernel(const double *x, double *y, size_t n, size_t nchan, size_t pitch, IirCoef k,
+                                                 double *state)
+{
+    constexpr int NI = CW / 4; // load instructions per chunk: each covers 4 rows x 16 samples
+    __shared__ double tile[CW * IPITCH];
+    const unsigned l = threadIdx.x, sub = l / IC, col = l % IC, cl = l % CW;
+    const size_t c0 = (size_t)blockIdx.x * CW, c = c0 + cl;
+    double s[4] = {0, 0, 0, 0};
+    const bool carried = (KIND == K_LP || KIND == K_NOTCH) && state != nullptr && c < nchan;
+    if (carried)
+        for (int j = 0; j < 4; j++) s[j] = state[c * 4 + j];
+    // load/store role of this lane: rows c0 + 4i + sub (i < NI), sample s0 + col
+    const size_t row0 = (c0 + sub) * pitch + col;
+    double nxt[NI];
+    auto load = [&](size_t s0) {
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            nxt[i] = (c0 + 4 * i + sub < nchan && s0 + col < n) ? x[row0 + (size_t)(4 * i) * pitch + s0] : 0.0;
+    };
+    load(0);
+    for (size_t s0 = 0; s0 < n; s0 += IC) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) tile[(4 * i + sub) * IPITCH + col] = nxt[i];
+        wave_lds_sync();
+        if (s0 + IC < n) load(s0 + IC);
+        double v[IC];
+#pragma unroll
+        for (int j = 0; j < IC; j++) v[j] = tile[cl * IPITCH + j];
+        if (s0 + IC <= n) iir_chunk<KIND, false>(v, s, k, s0, n);
+        else iir_chunk<KIND, true>(v, s, k, s0, n);
+        wave_lds_sync();
+        if (l < CW) {
+#pragma unroll
+            for (int j = 0; j < IC; j++) tile[cl * IPITCH + j] = v[j];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            if (c0 + 4 * i + sub < nchan && s0 + col < n) y[row0 + (size_t)(4 * i) * pitch + s0] = tile[(4 * i + sub) * IPITCH + col];
+        wave_lds_sync();
+    }
+    if (carried && l < CW)
+        for (int j = 0; j < 4; j++) state[c * 4 + j] = s[j];
+}
+
+template <int KIND>
+void launch_iir(int cw, const double *x, double *y, size_t n, size_t nchan, size_t pitch, const IirCoef &k, double *state,
+                hipStream_t s)
+{
+    dim3 grid((unsigned)((nchan + cw - 1) / cw)), block(64);
+    if (cw == 64) iir_kernel<KIND, 64><<<grid, block, 0, s>>>(x, y, n, nchan, pitch, k, state);
+    else if (cw == 16) iir_kernel<KIND, 16><<<grid, block, 0, s>>>(x, y, n, nchan, pitch, k, state);
+    else iir_kernel<KIND, 4><<<grid, block, 0, s>>>(x, y, n, nchan, pitch, k, state);
+}
+
+// ---- normalize (Normalize.cpp:7-22): size_t running maximum, then (x / max)*2 - 1 ----
+// The running maximum only ever takes the values (size_t)|x[i]| of samples that exceed it, so
+// its final value is max((size_t)prev_max, max_i (size_t)|x[i]|) in any order: a reduction.
+// Non-negative doubles order like their bit patterns, hence the integer atomic.
+__global__ void norm_init_kernel(double *mx, size_t nchan)
+{
+    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nchan) mx[c] = (double)(unsigned long long)mx[c]; // size_t max = prev_max
+}
+
+constexpr int NORM_PER_THREAD = 8;
+
+__global__ __launch_bounds__(256) void norm_max_kernel(const double *x, size_t n, size_t nchan, size_t pitch, double *mx)
+{
+    const size_t c = (size_t)blockIdx.y + (size_t)blockIdx.z * gridDim.y;
+    if (c >= nchan) return;
+    const double *xp = x + c * pitch;
+    size_t i0 = (size_t)blockIdx.x * (256 * NORM_PER_THREAD) + threadIdx.x;
+    double m = 0.0;
+    for (int j = 0; j < NORM_PER_THREAD; j++) {
+        size_t i = i0 + (size_t)j * 256;
+        if (i < n) {
+            double a = trunc(fabs(xp[i]));
+            if (a > m) m = a; // false for NaN, like `max < abs(x)`
+        }
+    }
+    unsigned long long b = (unsigned long long)__double_as_longlong(m);
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(b, o);
+        b = t > b ? t : b;
+    }
+    if ((threadIdx.x & 63) == 0 && b != 0) atomicMax(reinterpret_cast<unsigned long long *>(mx + c), b);
+}
+
+__global__ __launch_bounds__(256) void norm_scale_kernel(double *x, size_t n, size_t nchan, size_t pitch, const double *mx)
+{
+    const size_t c = (size_t)blockIdx.y + (size_t)blockIdx.z * gridDim.y;
+    if (c >= nchan) return;
+    double *xp = x + c * pitch;
+    const double m = mx[c];
+    size_t i0 = (size_t)blockIdx.x * (256 * NORM_PER_THREAD) + threadIdx.x;
+    for (int j = 0; j < NORM_PER_THREAD; j++) {
+        size_t i = i0 + (size_t)j * 256;
+        if (i < n) xp[i] = (xp[i] / m) * 2.0 - 1.0;
+    }
+}
+
+// ---- fifth_order_filter::decimate(double*, size_t, size_t) (fifth_order_filter.cpp:65-88) ----
+// Per pass: data[0] = F(state); then for i = 2, 4, ... < n the window slides by one (even) sample pair
+// and data[i/2] = F(window).  With pair(j) = (data[2j-2], data[2j]) for j >= 2, pair(1) = (new data[0],
+// data[2]), pair(0) = (r_e, r_f), pair(-1) = (r_c, r_d) at pass entry, output k = F(pair(k-2), pair(k-1),
+// pair(k)): independent outputs.  In place: output k lands below every sample a later output reads, so one
+// workgroup walks the row in chunks, loads before a barrier, stores after it.
+struct Pair {
+    double e, f;
+};
+
+__device__ __forceinline__ Pair fifth_pair(const double *d, long j, const double (&s)[6], double d0n)
+{
+    if (j == -1) return {s[2], s[3]};
+    if (j == 0) return {s[4], s[5]};
+    if (j == 1) return {d0n, d[2]};
+    return {d[2 * j - 2], d[2 * j]};
+}
+
+__device__ __forceinline__ double fifth_out(Pair ab, Pair cd, Pair ef)
+{
+    const double a = 1, b = 5, c = 10, d = 11;
+    return ((a * (ab.e + ef.f)) + ((ab.f + ef.e) * b) + ((cd.e + cd.f) * c)) / d;
+}
+
+__global__ __launch_bounds__(256) void fifth_kernel(double *data, size_t n, size_t pitch, size_t by, double *state)
+{
+    const size_t c = blockIdx.x;
+    double *d = data + c * pitch;
+    double s[6];
+    for (int j = 0; j < 6; j++) s[j] = state[c * 6 + j];
+    const long K = (long)((n - 1) / 2); // iterations i = 2k < n, k = 1..K
+    for (size_t dec = 2; dec <= by; dec *= 2) {
+        const double d0n = fifth_out({s[0], s[1]}, {s[2], s[3]}, {s[4], s[5]});
+        double ns[6] = {s[0], s[1], s[2], s[3], s[4], s[5]};
+        if (K >= 1) { // the window of the last iteration, read before anything is overwritten
+            Pair p0 = fifth_pair(d, K - 2, s, d0n), p1 = fifth_pair(d, K - 1, s, d0n), p2 = fifth_pair(d, K, s, d0n);
+            ns[0] = p0.e, ns[1] = p0.f, ns[2] = p1.e, ns[3] = p1.f, ns[4] = p2.e, ns[5] = p2.f;
+        }
+        __syncthreads();
+        for (long k0 = 1; k0 <= K; k0 += 256) {
+            long k = k0 + threadIdx.x;
+            double out = 0;
+            if (k <= K) out = fifth_out(fifth_pair(d, k - 2, s, d0n), fifth_pair(d, k - 1, s, d0n), fifth_pair(d, k, s, d0n));
+            __syncthreads();
+            if (k <= K) d[k] = out;
+        }
+        if (threadIdx.x == 0) d[0] = d0n;
+        for (int j = 0; j < 6; j++) s[j] = ns[j];
+        __syncthreads(); // the next pass reads what this one wrote
+    }
+    if (threadIdx.x == 0)
+        for (int j = 0; j < 6; j++) state[c * 6 + j] = s[j];
+}
+
+// ---- fft (FFT.cpp:7-28): recursive radix-2 DIT == bit-reversal + log2 N butterfly stages with the
+// same arithmetic per butterfly: t = polar(1, -2*PI*k/len) * odd; (even + t, even - t).
+// (-2*PI*k)/len == (-2*PI*(k*N/len))/N bit for bit (powers of two), so one table of N/2 twiddles serves
+// every stage; it is computed once per (device, N) and kept.  One workgroup per transform, data and
+// twiddles in LDS; three stages at a time on 8 elements in registers (which butterflies meet in one
+// thread changes nothing in their arithmetic), so the data crosses LDS ceil(log2 N / 3) times.
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__global__ void fft_twiddle_kernel(v2d *tw, unsigned N)
+{
+    unsigned j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N / 2) return;
+    double theta = -2 * 3.141592653589793238460 * (double)j / (double)N, sn, cs;
+    sdrx_sincos(theta, &sn, &cs);
+    tw[j] = v2d{cs, sn}; // std::polar(1.0, theta)
+}
+
+__device__ __forceinline__ unsigned fft_pad(unsigned i) { return i + (i >> 3); } // one spare slot per 8: odd LDS strides
+
+template <int R> __device__ __forceinline__ void fft_group(v2d *x, const v2d *tw, unsigned st, unsigned log2n, unsigned N)
+{
+    constexpr unsigned E = 1u << R;
+    const unsigned half = 1u << st;
+    for (unsigned t = threadIdx.x; t < N / E; t += 256) {
+        const unsigned lo = t & (half - 1), base = ((t >> st) << (st + R)) + lo;
+        v2d v[E];
+#pragma unroll
+        for (unsigned q = 0; q < E; q++) v[q] = x[fft_pad(base + q * half)];
+#pragma unroll
+        for (unsigned r = 0; r < (unsigned)R; r++) { // stage st + r pairs the elements whose q differs in bit r
+            const unsigned shift = log2n - 1 - st - r;
+#pragma unroll
+            for (unsigned q = 0; q < E; q++) {
+                if (q & (1u << r)) continue;
+                const unsigned k = ((q & ((1u << r) - 1)) << st) + lo;
+                const v2d w = tw[k << shift], o = v[q | (1u << r)], e = v[q];
+                const double tr = w.x * o.x - w.y * o.y, ti = w.x * o.y + w.y * o.x;
+                v[q] = v2d{e.x + tr, e.y + ti};
+                v[q | (1u << r)] = v2d{e.x - tr, e.y - ti};
+            }
+        }
+#pragma unroll
+        for (unsigned q = 0; q < E; q++) x[fft_pad(base + q * half)] = v[q];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void fft_kernel(double *iq, const v2d *__restrict__ tw_g, unsigned N, unsigned log2n,
+                                                  size_t pitch)
+{
+    extern __shared__ v2d fft_lds[];
+    v2d *tw = fft_lds, *x = fft_lds + N / 2;
+    v2d *g = reinterpret_cast<v2d *>(iq) + (size_t)blockIdx.x * pitch;
+    for (unsigned i = threadIdx.x; i < N; i += 256) x[fft_pad(__brev(i) >> (32 - log2n))] = g[i];
+    for (unsigned j = threadIdx.x; j < N / 2; j += 256) tw[j] = tw_g[j];
+    __syncthreads();
+    unsigned st = 0;
+    for (; st + 3 <= log2n; st += 3) fft_group<3>(x, tw, st, log2n, N);
+    if (log2n - st == 2) fft_group<2>(x, tw, st, log2n, N);
+    if (log2n - st == 1) fft_group<1>(x, tw, st, log2n, N);
+    for (unsigned i = threadIdx.x; i < N; i += 256) g[i] = x[fft_pad(i)];
+}
+
+constexpr int FFT_MAX_LOG2 = 12;
+static_assert((1 << FFT_MAX_LOG2) == SDRX_FFT_MAX, "table size");
+v2d *g_fft_tw[64][FFT_MAX_LOG2 + 1];
+bool g_fft_attr[64];
+std::mutex g_fft_mu;
+
+// twiddle table of one length on the current device; the first call for a length allocates and fills it
+int fft_twiddles(unsigned log2n, hipStream_t s, const v2d **out)
+{
+    int dev = 0;
+    SDRX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) {
+        set_error("sdrx_fft_dev: device index %d", dev);
+        return SDRX_EUNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lk(g_fft_mu);
+    if (!g_fft_attr[dev]) {
+        SDRX_HIP(hipFuncSetAttribute((const void *)fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        g_fft_attr[dev] = true;
+    }
+    if (!g_fft_tw[dev][log2n]) {
+        const unsigned N = 1u << log2n;
+        v2d *p = nullptr;
+        SDRX_HIP(hipMalloc(&p, sizeof(v2d) * (N / 2)));
+        fft_twiddle_kernel<<<(N / 2 + 255) / 256, 256, 0, s>>>(p, N);
+        SDRX_HIP(hipGetLastError());
+        SDRX_HIP(hipStreamSynchronize(s)); // later calls may come on other streams
+        g_fft_tw[dev][log2n] = p;
+    }
+    *out = g_fft_tw[dev][log2n];
+    return SDRX_OK;
+}
+
+int check_rows(const void *p, size_t n, size_t nchan, size_t pitch, const char *who)
+{
+    if (nchan == 0 || n == 0) return 1; // nothing to do
+    if (!p) {
+        set_error("%s: null buffer", who);
+        return SDRX_EINVAL;
+    }
+    if (nchan > 1 && pitch < n) {
+        set_error("%s: pitch %zu < n %zu", who, pitch, n);
+        return SDRX_EINVAL;
+    }
+    if (nchan >= (1ull << 31)) {
+        set_error("%s: too many channels", who);
+        return SDRX_EUNSUPPORTED;
+    }
+    return 0;
+}
+
+void fold_channels(size_t nchan, unsigned &gy, unsigned &gz)
+{
+    gy = (unsigned)(nchan < 65535 ? nchan : 65535);
+    gz = (unsigned)((nchan + gy - 1) / gy);
+}
+
+} // namespace
+} // namespace sdrx
+
+using namespace sdrx;
+
+extern "C" int sdrx_iir_dev(int kind, const double *coef, const double *x, double *y, size_t n, size_t nchan, size_t pitch,
+                            double *state, void *stream)
+{
+    int r = check_rows(x, n, nchan, pitch, "sdrx_iir_dev");
+    if (r) return r < 0 ? r : SDRX_OK;
+    if (!y) {
+        set_error("sdrx_iir_dev: null output");
+        return SDRX_EINVAL;
+    }
+    static const int ncoef[4] = {1, 1, 5, 1};
+    if (kind < 0 || kind > 3 || !coef) {
+        set_error("sdrx_iir_dev: kind %d / coefficients", kind);
+        return SDRX_EINVAL;
+    }
+    IirCoef k = {{0, 0, 0, 0, 0}};
+    for (int j = 0; j < ncoef[kind]; j++) k.c[j] = coef[j];
+    // rows per wave: the largest of 64 / 16 / 4 that still gives every SIMD of the part (1024) a wave
+    int cw = nchan >= 64 * 1024 ? 64 : (nchan >= 16 * 1024 ? 16 : 4);
+    if (const char *e = getenv("SDRX_IIR_CW")) {
+        int v = atoi(e);
+        if (v == 64 || v == 16 || v == 4) cw = v;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (kind) {
+    case K_DC: launch_iir<K_DC>(cw, x, y, n, nchan, pitch, k, state, s); break;
+    case K_LP: launch_iir<K_LP>(cw, x, y, n, nchan, pitch, k, state, s); break;
+    case K_NOTCH: launch_iir<K_NOTCH>(cw, x, y, n, nchan, pitch, k, state, s); break;
+    default: launch_iir<K_INT>(cw, x, y, n, nchan, pitch, k, state, s); break;
+    }
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+extern "C" double sdrx_lowpass1_coef(double cutoff_frequency, double delta_time)
+{
+    return 1.0 - exp(-delta_time * cutoff_frequency); // LowPassFilter.cpp:9
+}
+
+extern "C" void sdrx_notch_design(double notch_bw, double center_freq, double *coef5)
+{
+    // NotchFilter.cpp:7-16 (its own 3.14159)
+    double R = 1.0 * notch_bw;
+    double K = (1 - 2 * R * cos(2.0 * 3.14159 * center_freq) + R * R) / (2 - 2 * cos(2 * 3.14159 * center_freq));
+    coef5[0] = K;
+    coef5[1] = -2.0 * K * cos(2.0 * 3.14159 * center_freq);
+    coef5[2] = K;
+    coef5[3] = 2.0 * R * cos(2.0 * 3.14159 * center_freq);
+    coef5[4] = -(R * R);
+}
+
+extern "C" int sdrx_normalize_dev(double *x, size_t n, size_t nchan, size_t pitch, double *max_inout, void *stream)
+{
+    int r = check_rows(x, n, nchan, pitch, "sdrx_normalize_dev");
+    if (r < 0) return r;
+    if (nchan == 0) return SDRX_OK;
+    if (!max_inout) {
+        set_error("sdrx_normalize_dev: null max_inout");
+        return SDRX_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    norm_init_kernel<<<(unsigned)((nchan + 255) / 256), 256, 0, s>>>(max_inout, nchan);
+    if (n) {
+        unsigned gy, gz;
+        fold_channels(nchan, gy, gz);
+        dim3 grid((unsigned)((n + 256 * NORM_PER_THREAD - 1) / (256 * NORM_PER_THREAD)), gy, gz);
+        norm_max_kernel<<<grid, 256, 0, s>>>(x, n, nchan, pitch, max_inout);
+        norm_scale_kernel<<<grid, 256, 0, s>>>(x, n, nchan, pitch, max_inout);
+    }
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+extern "C" int sdrx_fifth_order_decimate_dev(double *data, size_t n, size_t nchan, size_t pitch, size_t decimate_by,
+                                             double *state6, void *stream)
+{
+    int r = check_rows(data, n, nchan, pitch, "sdrx_fifth_order_decimate_dev");
+    if (r) return r < 0 ? r : SDRX_OK;
+    if (!state6) {
+        set_error("sdrx_fifth_order_decimate_dev: null state");
+        return SDRX_EINVAL;
+    }
+    if (decimate_by < 2) return SDRX_OK; // no pass runs (fifth_order_filter.cpp:70)
+    fifth_kernel<<<(unsigned)nchan, 256, 0, (hipStream_t)stream>>>(data, n, pitch, decimate_by, state6);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+extern "C" int sdrx_fft_dev(double *iq, size_t n, size_t nchan, size_t pitch, void *stream)
+{
+    int r = check_rows(iq, n, nchan, pitch, "sdrx_fft_dev");
+    if (r) return r < 0 ? r : SDRX_OK;
+    if (n & (n - 1) || n > SDRX_FFT_MAX) {
+        set_error("sdrx_fft_dev: length %zu is not a power of two <= %d", n, SDRX_FFT_MAX);
+        return SDRX_EUNSUPPORTED;
+    }
+    if (n == 1) return SDRX_OK;
+    unsigned log2n = 0;
+    while ((1ull << log2n) < n) log2n++;
+    const v2d *tw = nullptr;
+    int rc = fft_twiddles(log2n, (hipStream_t)stream, &tw);
+    if (rc != SDRX_OK) return rc;
+    size_t lds = (n / 2 + n + n / 8 + 1) * sizeof(v2d);
+    fft_kernel<<<(unsigned)nchan, 256, lds, (hipStream_t)stream>>>(iq, tw, (unsigned)n, log2n, pitch);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}

@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(256) deframe_kernel(const uint8_t *__restrict_
         if (len > 250) {
             kind = 2;
             p = q + 1;
+            __syncthreads(); // every wave has read the header before the next search refills the window
         } else {
             crc = to_byte(hdr + 24);
             if (tid < 250) pkt[tid] = (uint8_t)to_byte(hdr + 32 + 8 * tid);

@@ -169,6 +169,65 @@ def deframe(bits, crc_enable=True, max_events=1024):
     return out
 
 
+# ---- DigitalSignalProcessing primitives on (nchan, n) float64 device tensors (sdrx.h: sdrx_iir_dev ...) ----
+IIR_DC_BLOCK, IIR_LOWPASS, IIR_NOTCH, IIR_INTEGRATE = 0, 1, 2, 3
+FFT_MAX = 4096
+
+
+def _rows(x):
+    assert x.dtype == torch.float64 and x.dim() == 2 and x.is_contiguous()
+    return x.shape
+
+
+def iir(kind, coef, x, y=None, state=None):
+    """DC_Filter / LowPassFilter / NotchFilter / FirstOrderDigitalIntegration over every row of x (in place when y is
+    None).  coef: host floats; state: (nchan, 4) float64 device tensor carried between calls (lowpass, notch)."""
+    nchan, n = _rows(x)
+    y = x if y is None else y
+    assert y.shape == x.shape and y.dtype == torch.float64 and y.is_contiguous()
+    if state is not None:
+        assert state.dtype == torch.float64 and state.is_contiguous() and state.numel() == nchan * 4
+    coef = np.ascontiguousarray(np.atleast_1d(coef), dtype=np.float64)
+    _lib.check(_lib.lib().sdrx_iir_dev(int(kind), coef.ctypes.data, _ptr(x), _ptr(y), n, nchan, n,
+                                       _ptr(state) if state is not None else None, _stream()), "sdrx_iir_dev")
+    return y
+
+
+def lowpass1_coef(cutoff, dt):
+    return float(_lib.lib().sdrx_lowpass1_coef(cutoff, dt))
+
+
+def notch_design(bw, fc):
+    c = np.zeros(5)
+    _lib.lib().sdrx_notch_design(bw, fc, c.ctypes.data)
+    return c
+
+
+def normalize(x, max_inout):
+    """normalize() over every row of x in place; max_inout: (nchan,) float64 device tensor, prev_max in, max out."""
+    nchan, n = _rows(x)
+    assert max_inout.dtype == torch.float64 and max_inout.is_contiguous() and max_inout.numel() == nchan
+    _lib.check(_lib.lib().sdrx_normalize_dev(_ptr(x), n, nchan, n, _ptr(max_inout), _stream()), "sdrx_normalize_dev")
+    return x
+
+
+def fifth_order_decimate(x, by, state):
+    """fifth_order_filter::decimate over every row in place; state: (nchan, 6) float64 device tensor.  Returns n // by."""
+    nchan, n = _rows(x)
+    assert state.dtype == torch.float64 and state.is_contiguous() and state.numel() == nchan * 6
+    _lib.check(_lib.lib().sdrx_fifth_order_decimate_dev(_ptr(x), n, nchan, n, int(by), _ptr(state), _stream()),
+               "sdrx_fifth_order_decimate_dev")
+    return n // int(by)
+
+
+def fft(z):
+    """fft() over every row of z (complex128, (nchan, n), n a power of two <= FFT_MAX), in place."""
+    assert z.dtype == torch.complex128 and z.dim() == 2 and z.is_contiguous()
+    nchan, n = z.shape
+    _lib.check(_lib.lib().sdrx_fft_dev(_ptr(z), n, nchan, n, _stream()), "sdrx_fft_dev")
+    return z
+
+
 class PskBank:
     """nchan independent BPSK or QPSK demodulators (BPSK.cpp:148-176 / QPSK.cpp:190-219), device resident."""
 

@@ -83,6 +83,24 @@ def lib():
     L.orc_frame.restype = C.c_int
     L.orc_fir_execute_fma.argtypes = [_f64, C.c_int, _f64, _f64, _sz]
     L.orc_fir_execute_fma.restype = None
+    L.orc_dc_block.argtypes = [_f64, _f64, _sz, C.c_double]
+    L.orc_dc_block.restype = None
+    L.orc_lowpass1_coef.argtypes = [C.c_double, C.c_double]
+    L.orc_lowpass1_coef.restype = C.c_double
+    L.orc_lowpass1.argtypes = [_f64, _f64, _sz, C.c_double, _f64]
+    L.orc_lowpass1.restype = None
+    L.orc_notch_design.argtypes = [C.c_double, C.c_double, _f64]
+    L.orc_notch_design.restype = None
+    L.orc_notch.argtypes = [_f64, _sz, _f64, _f64]
+    L.orc_notch.restype = None
+    L.orc_integrate.argtypes = [_f64, _sz, C.c_double]
+    L.orc_integrate.restype = None
+    L.orc_normalize.argtypes = [_f64, _sz, C.c_double]
+    L.orc_normalize.restype = C.c_double
+    L.orc_fifth_order_decimate.argtypes = [_f64, _sz, _sz, _f64]
+    L.orc_fifth_order_decimate.restype = _sz
+    L.orc_fft.argtypes = [_f64, _sz, C.c_int]
+    L.orc_fft.restype = None
     L.orc_am_modulate.argtypes = [_u8, _sz, _f64, _sz]
     L.orc_am_modulate.restype = None
     L.orc_am_demodulate.argtypes = [_f64, _f64, _u8, _sz, _sz]
@@ -300,6 +318,63 @@ def crc8(data):
     return int(lib().orc_crc8(data, data.size))
 
 
+# ---- DSP primitives (DigitalSignalProcessing/*.cpp), single channel, numpy in / numpy out
+
+def dc_block(x, R=0.995):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros_like(x)
+    lib().orc_dc_block(x, y, x.size, R)
+    return y
+
+
+def lowpass1(x, epow, state):
+    """state: float64[1], updated"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros_like(x)
+    lib().orc_lowpass1(x, y, x.size, epow, state)
+    return y
+
+
+def notch_design(bw, fc):
+    c = np.zeros(5)
+    lib().orc_notch_design(bw, fc, c)
+    return c
+
+
+def notch(x, coef, state):
+    """state: float64[4] = x_1,x_2,y_1,y_2, updated"""
+    y = np.array(x, dtype=np.float64)
+    lib().orc_notch(y, y.size, np.ascontiguousarray(coef, dtype=np.float64), state)
+    return y
+
+
+def integrate(x, tstep):
+    y = np.array(x, dtype=np.float64)
+    lib().orc_integrate(y, y.size, tstep)
+    return y
+
+
+def normalize(x, prev_max=0.0):
+    y = np.array(x, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        m = lib().orc_normalize(y, y.size, prev_max)
+    return y, m
+
+
+def fifth_order_decimate(x, by, state):
+    """state: float64[6] = r_a..r_f, updated; returns (array after the in-place passes, returned length)"""
+    y = np.array(x, dtype=np.float64)
+    r = lib().orc_fifth_order_decimate(y, y.size, by, state)
+    return y, r
+
+
+def fft(iq, math_mode=MATH_SHARED):
+    """iq: complex128[n], n a power of two"""
+    y = np.array(iq, dtype=np.complex128)
+    lib().orc_fft(y.view(np.float64), y.size, math_mode)
+    return y
+
+
 def ref():
     global _ref
     if _ref is not None:
@@ -313,6 +388,20 @@ def ref():
     R.ref_frame.restype = C.c_int
     R.ref_deframe.argtypes = [_u8, _sz, C.c_int, _sz, _i64, _i32, _u8, _u8, _u8, _u64]
     R.ref_deframe.restype = None
+    R.ref_dc_block.argtypes = [_f64, _f64, _sz, C.c_double]
+    R.ref_lowpass1_new.argtypes = [C.c_double, C.c_double]
+    R.ref_lowpass1_new.restype = C.c_void_p
+    R.ref_lowpass1_free.argtypes = [C.c_void_p]
+    R.ref_lowpass1.argtypes = [C.c_void_p, _f64, _f64, _sz]
+    R.ref_notch.argtypes = [C.c_double, C.c_double, _f64, _sz]
+    R.ref_integrate.argtypes = [C.c_double, _f64, _sz]
+    R.ref_normalize.argtypes = [_f64, _sz, C.c_double]
+    R.ref_normalize.restype = C.c_double
+    R.ref_fifth_new.restype = C.c_void_p
+    R.ref_fifth_free.argtypes = [C.c_void_p]
+    R.ref_fifth_decimate.argtypes = [C.c_void_p, _f64, _sz, _sz]
+    R.ref_fifth_decimate.restype = _sz
+    R.ref_fft.argtypes = [_f64, _sz]
     R.ref_fir_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
     R.ref_fir_new.restype = C.c_void_p
     R.ref_fir_error.argtypes = [C.c_void_p]

@@ -451,6 +451,118 @@ def test_rtlfm_int16_chain(ds, rot):
             assert np.array_equal(st_dev[c], sts[c]), (c, lo, hi)
 
 
+# =============================================================================== DSP primitives
+
+def _rows_dev(a):
+    return torch.tensor(np.ascontiguousarray(a), device="cuda")
+
+
+@pytest.mark.parametrize("cw", [4, 16, 64])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 15, 16, 17, 18, 33, 1000, 4099])
+def test_dsp_recurrences_bit_exact(n, cw, monkeypatch):
+    """(cw = rows per wave: the launcher's three kernel shapes.)  DC_Filter, LowPassFilter, NotchFilter, FirstOrderDigitalIntegration: 70 channels (more than one wave, ragged
+    last wave), three calls in a row so that the carried state (lowpass, notch) and the restart (dc block,
+    integrate) are both seen; every row equals the oracle's bit for bit."""
+    monkeypatch.setenv("SDRX_IIR_CW", str(cw))
+    rng = np.random.default_rng(1000 + n)
+    nchan = 70
+    epow = device.lowpass1_coef(3000.0, 1.0 / 48000.0)
+    assert epow == L.orc_lowpass1_coef(3000.0, 1.0 / 48000.0)
+    coef = device.notch_design(0.9, 0.05)
+    assert np.array_equal(coef, O.notch_design(0.9, 0.05))
+    st_lp, st_no = np.zeros((nchan, 1)), np.zeros((nchan, 4))
+    d_lp = torch.zeros(nchan, 4, dtype=torch.float64, device="cuda")
+    d_no = torch.zeros(nchan, 4, dtype=torch.float64, device="cuda")
+    for call in range(3):
+        x = rng.normal(0, 30, (nchan, n)) + 2.5
+        xd = _rows_dev(x)
+        # x -> y and in place give the same rows
+        y = torch.empty_like(xd)
+        device.iir(device.IIR_DC_BLOCK, 0.995, xd, y)
+        assert np.array_equal(y.cpu().numpy(), np.stack([O.dc_block(r, 0.995) for r in x]).reshape(nchan, n))
+        z = xd.clone()
+        device.iir(device.IIR_DC_BLOCK, 0.995, z)
+        assert torch.equal(z, y)
+        z = xd.clone()
+        device.iir(device.IIR_INTEGRATE, 1.0 / 48000.0, z)
+        assert np.array_equal(z.cpu().numpy(), np.stack([O.integrate(r, 1.0 / 48000.0) for r in x]).reshape(nchan, n))
+        device.iir(device.IIR_LOWPASS, epow, xd, y, state=d_lp)
+        want = np.stack([O.lowpass1(x[c], epow, st_lp[c]) for c in range(nchan)]).reshape(nchan, n)
+        assert np.array_equal(y.cpu().numpy(), want)
+        assert np.array_equal(d_lp.cpu().numpy()[:, 0], st_lp[:, 0])
+        z = xd.clone()
+        device.iir(device.IIR_NOTCH, coef, z, state=d_no)
+        want = np.stack([O.notch(x[c], coef, st_no[c]) for c in range(nchan)]).reshape(nchan, n)
+        assert np.array_equal(z.cpu().numpy(), want)
+        assert np.array_equal(d_no.cpu().numpy(), st_no)
+
+
+@pytest.mark.parametrize("n,scale,prev", [(0, 1.0, 3.7), (1, 7.9, 3.5), (100, 50.0, 0.0), (100, 50.0, 1e4), (33, 0.2, 0.0),
+                                           (5000, 1e6, 0.0), (2049, 300.0, 12.0)])
+def test_dsp_normalize_bit_exact(n, scale, prev):
+    """normalize(): the size_t running maximum as a reduction (also rows whose maximum truncates to 0: division by
+    zero like the reference), returned maximum and scaled samples bit-identical."""
+    rng = np.random.default_rng(n + int(scale))
+    nchan = 9
+    x = rng.normal(0, scale, (nchan, n))
+    xd = _rows_dev(x)
+    mx = torch.full((nchan,), prev, dtype=torch.float64, device="cuda")
+    device.normalize(xd, mx)
+    got, got_m = xd.cpu().numpy(), mx.cpu().numpy()
+    for c in range(nchan):
+        want, m = O.normalize(x[c], prev)
+        assert got_m[c] == m
+        assert np.array_equal(got[c], want, equal_nan=True)
+
+
+@pytest.mark.parametrize("n,by", [(1, 2), (2, 2), (3, 2), (4, 2), (5, 2), (64, 2), (513, 2), (514, 2), (515, 4), (1000, 8),
+                                  (5000, 4), (40, 1)])
+def test_dsp_fifth_order_decimate_bit_exact(n, by):
+    """fifth_order_filter::decimate(double*): in place, log2(by) passes over the same n, state carried across two
+    calls; whole row (written part and untouched tail) and the six state doubles bit-identical."""
+    rng = np.random.default_rng(n * 16 + by)
+    nchan = 5
+    st = np.zeros((nchan, 6))
+    d_st = torch.zeros(nchan, 6, dtype=torch.float64, device="cuda")
+    for call in range(2):
+        x = rng.normal(0, 10, (nchan, n))
+        xd = _rows_dev(x)
+        r = device.fifth_order_decimate(xd, by, d_st)
+        got = xd.cpu().numpy()
+        for c in range(nchan):
+            want, rw = O.fifth_order_decimate(x[c], by, st[c])
+            assert r == rw
+            assert np.array_equal(got[c], want), (call, c)
+        assert np.array_equal(d_st.cpu().numpy(), st)
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 64, 512, 1024, 4096])
+def test_dsp_fft(n):
+    """fft(): bit-identical to the oracle in shared-math mode (same butterflies, same twiddle arithmetic), within
+    1e-12 relative of the libm build (the reference's arithmetic, pinned to the compiled reference on the CPU)."""
+    rng = np.random.default_rng(n)
+    nchan = 7
+    z = rng.normal(0, 1, (nchan, n)) + 1j * rng.normal(0, 1, (nchan, n))
+    zd = torch.tensor(z, device="cuda")
+    device.fft(zd)
+    got = zd.cpu().numpy()
+    for c in range(nchan):
+        assert np.array_equal(got[c], O.fft(z[c], O.MATH_SHARED))
+        ref = O.fft(z[c], O.MATH_LIBM)
+        assert np.max(np.abs(got[c] - ref)) <= 1e-12 * max(1.0, np.abs(ref).max()) * np.log2(max(n, 2))
+
+
+def test_dsp_unsupported_and_empty():
+    z = torch.zeros(2, 12, dtype=torch.complex128, device="cuda")
+    with pytest.raises(RuntimeError):
+        device.fft(z)  # not a power of two
+    z = torch.zeros(1, 8192, dtype=torch.complex128, device="cuda")
+    with pytest.raises(RuntimeError):
+        device.fft(z)  # beyond SDRX_FFT_MAX
+    e = torch.zeros(0, 16, dtype=torch.float64, device="cuda")
+    device.iir(device.IIR_DC_BLOCK, 0.995, e)
+    device.normalize(e, torch.zeros(0, dtype=torch.float64, device="cuda"))
+
 # =============================================================================== bit-domain back end
 
 @pytest.mark.parametrize("crc_enable", [True, False])
@@ -479,6 +591,27 @@ def test_deframe_vs_oracle(crc_enable):
                 assert g[k] == want[k], (m, i, k, g[k], want[k])
             for k in ("pos", "kind", "len", "crc", "payload"):
                 assert np.array_equal(g[k], want[k]), (m, i, k)
+
+
+def test_deframe_dense_length_errors():
+    """Streams made almost only of unique words followed by a length above 250 (the reference's return -1 that
+    removes one bit), every 40 bits, on 96 channels: the event path without a crc check back to back with the
+    next window refill (it once lacked a barrier between the header read and that refill)."""
+    rng = np.random.default_rng(4242)
+    n, nchan = 30000, 96
+    uw = np.array([1, 1, 1, 1, 1, 0, 1, 0, 1, 1, 0, 0, 1, 1, 1, 0], dtype=np.uint8)
+    streams = rng.integers(0, 2, (nchan, n)).astype(np.uint8)
+    for c in range(nchan):
+        for q in range(int(rng.integers(0, 40)), n - 24, 40):
+            streams[c, q:q + 16] = uw
+            streams[c, q + 16:q + 24] = [1, 1, 1, 1, 1, 1, int(rng.integers(0, 2)), 1] if rng.random() < 0.8 else rng.integers(0, 2, 8)
+    got = device.deframe(torch.tensor(streams, device="cuda"), True, max_events=1024)
+    for c in range(0, nchan, 5):
+        want = O.deframe(streams[c], True, max_events=1024)
+        for k in ("events", "consumed", "zero_returns"):
+            assert got[c][k] == want[k], (c, k, got[c][k], want[k])
+        for k in ("pos", "kind", "len", "crc", "payload"):
+            assert np.array_equal(got[c][k], want[k]), (c, k)
 
 
 def test_deframe_edge_lengths_and_golden():

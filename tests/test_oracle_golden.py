@@ -420,3 +420,59 @@ def test_packetframer_bad_length():
     r = _feed_one_by_one(bad, crc_enable=False)
     assert r["events"] >= 1 and r["kind"][0] == 2 and r["pos"][0] == 0 and r["len"][0] == 255
 
+
+
+# ---- DSP primitives.  The reference holds no vector for them: the restatements are pinned to
+# the compiled reference in the build container (test_oracle_vs_ref.py::test_dsp_primitives_vs_reference); here,
+# their defining properties, which also run where /root/reference is absent.
+
+def test_dsp_primitive_restatements_properties():
+    rng = np.random.default_rng(77)
+    x = rng.normal(0, 5, 400) + 9.0
+    # DC blocker: y(0) = x(0); the difference equation holds sample for sample; a constant input decays like R^n
+    y = O.dc_block(x, 0.995)
+    assert y[0] == x[0]
+    assert np.array_equal(y[1:], np.array([x[i] - x[i - 1] + 0.995 * y[i - 1] for i in range(1, 400)]))
+    c = O.dc_block(np.full(50, 3.0), 0.5)
+    assert np.allclose(c, 3.0 * 0.5 ** np.arange(50), rtol=1e-12, atol=0)
+    # first-order low pass: step response 1 - (1 - ePow)^(n+1); state carried over a split call
+    e = O.lib().orc_lowpass1_coef(3000.0, 1.0 / 48000.0)
+    assert e == 1.0 - np.exp(-3000.0 / 48000.0)
+    st = np.zeros(1)
+    s1 = O.lowpass1(np.ones(100), e, st)
+    assert np.allclose(s1, 1 - (1 - e) ** np.arange(1, 101), rtol=1e-12)
+    st2 = np.zeros(1)
+    parts = np.concatenate([O.lowpass1(np.ones(37), e, st2), O.lowpass1(np.ones(63), e, st2)])
+    assert np.array_equal(parts, s1) and st2[0] == st[0]
+    # notch: first two samples of a block untouched and not in the delay line; difference equation otherwise
+    coef = O.notch_design(0.9, 0.05)
+    st = np.zeros(4)
+    y = O.notch(x, coef, st)
+    assert np.array_equal(y[:2], x[:2])
+    x1 = x2 = y1 = y2 = 0.0
+    for i in range(2, 400):
+        w = coef[0] * x[i] + coef[1] * x1 + coef[2] * x2 + coef[3] * y1 + coef[4] * y2
+        assert y[i] == w
+        x2, x1, y2, y1 = x1, x[i], y1, w
+    assert np.array_equal(st, [x1, x2, y1, y2])
+    # integrator: running sum scaled by the time step
+    t = 1.0 / 48000.0
+    y = O.integrate(x, t)
+    assert y[0] == x[0] and np.allclose(y, x[0] + t * np.concatenate([[0.0], np.cumsum(x[1:])]), rtol=1e-12)
+    # normalize: integer maximum, affine map
+    y, m = O.normalize(x, 0.0)
+    assert m == np.floor(np.abs(x).max()) and np.array_equal(y, (x / m) * 2.0 - 1.0)
+    assert O.normalize(x, 1e4)[1] == 1e4
+    # fifth-order decimator: steady state is the symmetric 1-5-10-10-5-1 window over every second sample, / 11
+    st = np.zeros(6)
+    y, r = O.fifth_order_decimate(x, 2, st)
+    assert r == 200
+    k = 10
+    a, b, c_, d_, e_, f = x[2 * k - 6], x[2 * k - 4], x[2 * k - 4], x[2 * k - 2], x[2 * k - 2], x[2 * k]
+    assert y[k] == ((1 * (a + f)) + ((b + e_) * 5) + ((c_ + d_) * 10)) / 11
+    assert np.array_equal(y[200:], x[200:])  # samples beyond the last written one keep their values
+    # fft: against numpy, both math modes; linearity
+    z = rng.normal(0, 1, 256) + 1j * rng.normal(0, 1, 256)
+    for mode in (O.MATH_LIBM, O.MATH_SHARED):
+        assert np.allclose(O.fft(z, mode), np.fft.fft(z), rtol=0, atol=1e-10)
+    assert np.max(np.abs(O.fft(z, O.MATH_SHARED) - O.fft(z, O.MATH_LIBM))) <= 1e-12 * 8 * np.abs(np.fft.fft(z)).max()

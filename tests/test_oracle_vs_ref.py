@@ -189,3 +189,66 @@ def test_deframe_vs_reference(seed, crc_enable):
             assert np.array_equal(a[k], b[k]), (n, k)
     assert O.deframe(full, crc_enable)["events"] > 5
 
+
+
+# ---- DSP primitives: DigitalSignalProcessing/*.cpp compiled from the reference ----
+
+def test_dsp_primitives_vs_reference():
+    R = O.ref()
+    rng = np.random.default_rng(31)
+    for n in (0, 1, 2, 3, 17, 1000):
+        x = rng.normal(0, 40, n) + 3.0
+        # DC_Filter
+        y_ref = np.zeros(n)
+        R.ref_dc_block(x.copy(), y_ref, n, 0.995)
+        assert np.array_equal(O.dc_block(x, 0.995), y_ref)
+        # FirstOrderDigitalIntegration (tStep = 1.0f / sampleRate)
+        a = x.copy()
+        R.ref_integrate(48000.0, a, n)
+        assert np.array_equal(O.integrate(x, 1.0 / 48000.0), a)
+    # LowPassFilter: one object, several blocks, state carried
+    h = R.ref_lowpass1_new(3000.0, 1.0 / 48000.0)
+    epow = O.lib().orc_lowpass1_coef(3000.0, 1.0 / 48000.0)
+    st = np.zeros(1)
+    for n in (5, 0, 1, 400):
+        x = rng.normal(0, 10, n)
+        y_ref = np.zeros(n)
+        R.ref_lowpass1(h, x, y_ref, n)
+        assert np.array_equal(O.lowpass1(x, epow, st), y_ref)
+    R.ref_lowpass1_free(h)
+    # NotchFilter: the reference's delay line is function-static (one per process): this is the
+    # only place the checker calls it, blocks in sequence, the oracle state in lockstep.
+    coef = O.notch_design(0.9, 0.05)
+    st = np.zeros(4)
+    for n in (7, 2, 1, 0, 300, 64):
+        x = rng.normal(0, 10, n)
+        b = x.copy()
+        R.ref_notch(0.9, 0.05, b, n)
+        assert np.array_equal(O.notch(x, coef, st), b)
+    # normalize: size_t running maximum
+    for n, scale, prev in ((100, 50.0, 0.0), (100, 50.0, 1e4), (33, 0.2, 0.0), (1, 7.9, 3.5), (64, 1e6, 0.0)):
+        x = rng.normal(0, scale, n)
+        b = x.copy()
+        with np.errstate(all="ignore"):
+            m_ref = R.ref_normalize(b, n, prev)
+        y, m = O.normalize(x, prev)
+        assert m == m_ref and np.array_equal(y, b, equal_nan=True)
+    # fifth_order_filter::decimate(double*): state carried over blocks, 1..3 passes
+    h = R.ref_fifth_new()
+    st = np.zeros(6)
+    for n, by in ((64, 2), (1, 2), (2, 2), (3, 2), (129, 4), (1000, 8), (5, 2), (40, 1)):
+        x = rng.normal(0, 10, n)
+        b = x.copy()
+        r_ref = R.ref_fifth_decimate(h, b, n, by)
+        y, r = O.fifth_order_decimate(x, by, st)
+        assert r == r_ref and np.array_equal(y, b)
+    R.ref_fifth_free(h)
+    # fft: libm mode is the reference's arithmetic bit for bit; the shared-math mode (the device's) within 1e-12
+    for n in (1, 2, 4, 64, 1024):
+        z = rng.normal(0, 1, n) + 1j * rng.normal(0, 1, n)
+        b = z.copy()
+        R.ref_fft(b.view(np.float64), n)
+        assert np.array_equal(O.fft(z, O.MATH_LIBM), b)
+        assert np.max(np.abs(O.fft(z, O.MATH_SHARED) - b), initial=0.0) <= 1e-12 * max(1.0, np.abs(b).max(initial=0.0)) * np.log2(max(n, 2))
+        if n >= 2:
+            assert np.allclose(b, np.fft.fft(z), rtol=0, atol=1e-9)
