@@ -118,6 +118,12 @@ size_t sdrx_fir_state_doubles(int num_taps); /* 2*(T-1)+2 */
 int sdrx_am_demod_dev(const double *re, const double *im, uint8_t *out, size_t n, size_t ds, void *stream);
 /* ones/zeros count (rtlsdr_receiver.cpp:2063-2074, ones_zeros.cu:28-52): *count (device int32, zeroed by the call) */
 int sdrx_ones_zeros_dev(const double *re, const double *im, size_t n, int32_t *count, void *stream);
+/* The same branch as the reference's CPU path runs it (rtlsdr_receiver.cpp:2063-2074): a confidence_counter walked
+ * by increment(1) / decrement(1) per sample, clamped to [0, max] after every step (confidence_counter.h:50-72); nchan
+ * independent streams (rows at `pitch`), counters[c] (device int32) read and written.  The walk is an ordered
+ * reduction of clamp maps: exact, whatever the rails do. */
+int sdrx_ones_zeros_confidence_dev(const double *re, const double *im, size_t n, size_t nchan, size_t pitch, int32_t max,
+                                   int32_t *counters, void *stream);
 /* FM<T>::demodulate (FM.h:83-148, repaired): w1/w2 device tables of ds doubles; out[n/ds] bits */
 int sdrx_fm_demod_dev(const double *re, const double *w1, const double *w2, uint8_t *out, size_t n, size_t ds,
                       void *stream);

@@ -18,6 +18,8 @@
 #include <DigitalSignalProcessing/Resample.h>
 #include <common/BBP_Block.h>
 #include <common/RingBuffer.h>
+#include <common/confidence_counter.h>
+#include <cmath>
 #include <crc/crc8.h>
 #include <network/PacketFramer.h>
 #include <DigitalSignalProcessing/DC_Filter.h>
@@ -246,6 +248,20 @@ void ref_deframe(const uint8_t *bits, size_t n, int crc_enable, size_t max_event
     summary[0] = nev;
     summary[1] = front;
     summary[2] = zero_returns;
+}
+
+// ---- the receiver's ones/zeros branch (rtlsdr_receiver.cpp:2063-2074) over the reference's confidence_counter ----
+int32_t ref_ones_zeros_confidence(const double *re, const double *im, size_t n, int32_t max, int32_t low, int32_t high,
+                                  int32_t start)
+{
+    confidence_counter cc(max, low, high); // starts at max / 2
+    cc.decrement(max);
+    cc.increment(start);
+    for (size_t i = 0; i < n; i++) {
+        if (sqrt(re[i] * re[i] + im[i] * im[i]) >= AM<RADIO_DATA_TYPE>::THRESHOLD) cc.increment(1);
+        else cc.decrement(1);
+    }
+    return cc.value();
 }
 
 // ---- DigitalSignalProcessing primitives ----

@@ -168,6 +168,22 @@ int32_t orc_ones_zeros(const double *re, const double *im, size_t n)
     return ones;
 }
 
+/* the same branch as the CPU path runs it: confidence_counter::increment(1) / decrement(1) per sample
+ * (rtlsdr_receiver.cpp:2063-2074, confidence_counter.h:50-72); returns the counter */
+int32_t orc_ones_zeros_confidence(const double *re, const double *im, size_t n, int32_t max, int32_t counter)
+{
+    for (size_t i = 0; i < n; i++) {
+        if (sqrt(re[i] * re[i] + im[i] * im[i]) >= 80.0) {
+            counter += 1;
+            if (counter > max) counter = max;
+        } else {
+            counter -= 1;
+            if (counter < 0) counter = 0;
+        }
+    }
+    return counter;
+}
+
 /* ---------------------------------------------------------------------- FM */
 
 void orc_fm_modulate(double tx_rate, double mark, double space, const uint8_t *bits, size_t len,

@@ -64,6 +64,7 @@ void orc_am_modulate(const uint8_t *bits, size_t len, double *out_real, size_t l
 size_t orc_am_demodulate(const double *re, const double *im, uint8_t *out, size_t n, size_t ds); /* AM.h:63-77 */
 /* rtlsdr_receiver.cpp:2063-2074: number of samples with envelope >= THRESHOLD */
 int32_t orc_ones_zeros(const double *re, const double *im, size_t n);
+int32_t orc_ones_zeros_confidence(const double *re, const double *im, size_t n, int32_t max, int32_t counter);
 
 /* ---- FM / FSK (streams/FM.h, repaired semantics: SURVEY section 8c) ---- */
 void orc_fm_modulate(double tx_rate, double mark, double space, const uint8_t *bits, size_t len,

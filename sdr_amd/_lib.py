@@ -61,6 +61,7 @@ SIGNATURES = {
     "sdrx_fir_state_doubles": (_sz, [C.c_int]),
     "sdrx_am_demod_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "sdrx_ones_zeros_dev": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
+    "sdrx_ones_zeros_confidence_dev": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_int32, _vp, _vp]),
     "sdrx_fm_demod_dev": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "sdrx_rtlfm_dev": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, C.c_int, _vp, _vp, _vp, _sz, _vp]),
     "sdrx_deframe_dev": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _sz, _vp, _vp]),

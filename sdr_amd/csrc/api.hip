@@ -177,6 +177,11 @@ extern "C" int sdrx_ones_zeros_dev(const double *re, const double *im, size_t n,
 {
     return launch_ones_zeros(re, im, n, count, (hipStream_t)stream);
 }
+extern "C" int sdrx_ones_zeros_confidence_dev(const double *re, const double *im, size_t n, size_t nchan, size_t pitch,
+                                              int32_t max, int32_t *counters, void *stream)
+{
+    return launch_ones_zeros_confidence(re, im, n, nchan, pitch, max, counters, (hipStream_t)stream);
+}
 extern "C" int sdrx_fm_demod_dev(const double *re, const double *w1, const double *w2, uint8_t *out, size_t n,
                                  size_t ds, void *stream)
 {

@@ -106,6 +106,96 @@ int launch_ones_zeros(const double *re, const double *im, size_t n, int32_t *cou
     return SDRX_OK;
 }
 
+// -------------------------------------------------------------------- ones / zeros confidence walk
+//
+// The receiver's CPU branch (rtlsdr_receiver.cpp:2063-2074) does not count: it walks a confidence_counter,
+// increment(1) for a sample with envelope >= 80, decrement(1) otherwise, clamped to [0, max] after EVERY step
+// (confidence_counter.h:50-72) -- order matters once the counter touches a rail.  A step is the map
+// x -> min(H, max(L, x + A)) with (A, L, H) = (+-1, 0, max), and such maps are closed under composition:
+//   (g2 o g1) = (A1 + A2, clamp(L1 + A2, L2, H2), clamp(H1 + A2, L2, H2)),
+// so a stream's walk is an ordered reduction.  Per wave: 64 coalesced loads, the 64 decisions of each as a
+// ballot mask parked in lane j, so lane l ends up with the decisions of samples [64 l, 64 l + 64) of the
+// wave's 4096; it composes them in order, the wave reduces in lane order by shuffles, the workgroup in wave
+// order through LDS.  One workgroup per channel.
+struct SatMap {
+    long long A, L, H;
+};
+constexpr long long SAT_INF = 1ll << 60;
+
+__device__ __forceinline__ long long clampll(long long v, long long lo, long long hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ SatMap sat_then(const SatMap &g1, const SatMap &g2) // g1 first, then g2
+{
+    return {g1.A + g2.A, clampll(g1.L + g2.A, g2.L, g2.H), clampll(g1.H + g2.A, g2.L, g2.H)};
+}
+
+constexpr int OZC_WAVES = 16;
+
+__global__ void __launch_bounds__(64 * OZC_WAVES) ones_zeros_confidence_kernel(const double *__restrict__ re_all,
+                                                                                const double *__restrict__ im_all, size_t n,
+                                                                                size_t pitch, double thr2, int32_t cmax,
+                                                                                int32_t *__restrict__ counters)
+{
+    __shared__ SatMap part[OZC_WAVES];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *re = re_all + (size_t)blockIdx.x * pitch, *im = im_all + (size_t)blockIdx.x * pitch;
+    SatMap run = {0, -SAT_INF, SAT_INF}; // (thread 0) the walk so far
+    for (size_t base = 0; base < n; base += 4096 * OZC_WAVES) {
+        const size_t wbase = base + (size_t)wave * 4096;
+        unsigned long long mine = 0;
+#pragma unroll 8
+        for (int j = 0; j < 64; j++) {
+            const size_t i = wbase + 64 * (size_t)j + lane;
+            bool one = false;
+            if (i < n) {
+                const double a = re[i], b = im[i];
+                one = (a * a + b * b) >= thr2; // rtlsdr_receiver.cpp:2066 (sqrt folded into thr2)
+            }
+            const unsigned long long m = __ballot(one);
+            if (lane == (unsigned)j) mine = m;
+        }
+        // this lane's run: samples wbase + 64 lane + [0, cnt)
+        const size_t seg = wbase + 64 * (size_t)lane;
+        const int cnt = seg >= n ? 0 : (n - seg < 64 ? (int)(n - seg) : 64);
+        SatMap g = {0, -SAT_INF, SAT_INF};
+        for (int b = 0; b < cnt; b++) {
+            const long long a = ((mine >> b) & 1ull) ? 1 : -1;
+            g.A += a;
+            g.L = clampll(g.L + a, 0, cmax);
+            g.H = clampll(g.H + a, 0, cmax);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { // lane i (earlier) absorbs lane i + off (later)
+            SatMap o = {__shfl_down(g.A, off), __shfl_down(g.L, off), __shfl_down(g.H, off)};
+            g = sat_then(g, o);
+        }
+        if (lane == 0) part[wave] = g;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int w = 0; w < OZC_WAVES; w++) run = sat_then(run, part[w]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        long long x = counters[blockIdx.x];
+        x = clampll(x + run.A, run.L, run.H);
+        counters[blockIdx.x] = (int32_t)x;
+    }
+}
+
+int launch_ones_zeros_confidence(const double *re, const double *im, size_t n, size_t nchan, size_t pitch, int32_t cmax,
+                                 int32_t *counters, hipStream_t s)
+{
+    if (nchan == 0 || n == 0) return SDRX_OK;
+    if (!re || !im || !counters || cmax < 0 || (nchan > 1 && pitch < n)) {
+        set_error("ones_zeros_confidence: bad argument");
+        return SDRX_EINVAL;
+    }
+    if (nchan > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
+    hipLaunchKernelGGL(ones_zeros_confidence_kernel, dim3((unsigned)nchan), dim3(64 * OZC_WAVES), 0, s, re, im, n, pitch,
+                       am_threshold_sq(), cmax, counters);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
 // -------------------------------------------------------------------------------- FSK correlator
 //
 // bit b: op1 = sum_{p=ds-1..0} x[b*ds+p]*w1[p], op2 likewise with w2 (each accumulator starts at 0

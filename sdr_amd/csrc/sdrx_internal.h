@@ -38,6 +38,8 @@ int launch_fir_mfma(const sdrx_fir_job *job, size_t n_out); // fir_mfma.hip: fas
 // demod_kernels.hip
 int launch_am_demod(const double *re, const double *im, uint8_t *out, size_t n, size_t ds, hipStream_t s);
 int launch_ones_zeros(const double *re, const double *im, size_t n, int32_t *count, hipStream_t s);
+int launch_ones_zeros_confidence(const double *re, const double *im, size_t n, size_t nchan, size_t pitch, int32_t cmax,
+                                 int32_t *counters, hipStream_t s);
 int launch_fm_demod(const double *re, const double *w1, const double *w2, uint8_t *out, size_t n, size_t ds,
                     hipStream_t s);
 

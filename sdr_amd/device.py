@@ -119,6 +119,17 @@ def ones_zeros(re, im, count):
                "sdrx_ones_zeros_dev")
 
 
+def ones_zeros_confidence(re, im, cmax, counters):
+    """re, im: (nchan, n) float64; counters: (nchan,) int32, walked in place like the receiver's CPU branch walks its
+    confidence_counter(cmax, ...) (rtlsdr_receiver.cpp:2063-2074)."""
+    assert re.dtype == torch.float64 and re.dim() == 2 and re.is_contiguous() and im.shape == re.shape and im.is_contiguous()
+    nchan, n = re.shape
+    assert counters.dtype == torch.int32 and counters.numel() == nchan and counters.is_contiguous()
+    _lib.check(_lib.lib().sdrx_ones_zeros_confidence_dev(_ptr(re), _ptr(im), n, nchan, n, int(cmax), _ptr(counters), _stream()),
+               "sdrx_ones_zeros_confidence_dev")
+    return counters
+
+
 def fm_demod(re, w1, w2, out, ds):
     _lib.check(_lib.lib().sdrx_fm_demod_dev(_ptr(re), _ptr(w1), _ptr(w2), _ptr(out), re.numel(), int(ds), _stream()),
                "sdrx_fm_demod_dev")

@@ -107,6 +107,8 @@ def lib():
     L.orc_am_demodulate.restype = _sz
     L.orc_ones_zeros.argtypes = [_f64, _f64, _sz]
     L.orc_ones_zeros.restype = C.c_int32
+    L.orc_ones_zeros_confidence.argtypes = [_f64, _f64, _sz, C.c_int32, C.c_int32]
+    L.orc_ones_zeros_confidence.restype = C.c_int32
     L.orc_fm_modulate.argtypes = [C.c_double, C.c_double, C.c_double, _u8, _sz, _f64, _sz]
     L.orc_fm_modulate.restype = None
     L.orc_fm_demodulate.argtypes = [C.c_double, C.c_double, C.c_double, _f64, _u8, _sz, _sz]
@@ -388,6 +390,8 @@ def ref():
     R.ref_frame.restype = C.c_int
     R.ref_deframe.argtypes = [_u8, _sz, C.c_int, _sz, _i64, _i32, _u8, _u8, _u8, _u64]
     R.ref_deframe.restype = None
+    R.ref_ones_zeros_confidence.argtypes = [_f64, _f64, _sz, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    R.ref_ones_zeros_confidence.restype = C.c_int32
     R.ref_dc_block.argtypes = [_f64, _f64, _sz, C.c_double]
     R.ref_lowpass1_new.argtypes = [C.c_double, C.c_double]
     R.ref_lowpass1_new.restype = C.c_void_p

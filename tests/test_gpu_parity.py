@@ -33,6 +33,10 @@ def G(golden, key):
     return np.array(golden[key])
 
 
+def _rows_dev(a):
+    return torch.tensor(np.ascontiguousarray(a), device="cuda")
+
+
 # =============================================================================== Filter
 
 @pytest.mark.parametrize("ftype,Fx,Fu", [(O.LPF, 1.0e5, None), (O.HPF, 3.0e5, None), (O.BPF, 1.0e5, 4.0e5)])
@@ -451,11 +455,37 @@ def test_rtlfm_int16_chain(ds, rot):
             assert np.array_equal(st_dev[c], sts[c]), (c, lo, hi)
 
 
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 4095, 4096, 4097, 65536, 65537, 200001])
+def test_ones_zeros_confidence_walk(n):
+    """sdrx_ones_zeros_confidence_dev: the receiver's CPU branch walks a confidence_counter one sample at a time,
+    clamped at 0 and max after every step; the device composes the clamp maps in order.  Six channels with maxima
+    small enough that the rails are hit all the time and one like the receiver's (500000), starts at either rail
+    and in the middle, envelopes on both sides of and exactly at the threshold: counters equal the literal loop's."""
+    rng = np.random.default_rng(7 + n)
+    cfg = [(10, 5, 0.5), (37, 0, 0.7), (37, 37, 0.3), (500000, 250000, 0.9), (1, 0, 0.5), (3, 3, 0.02)]
+    nchan = len(cfg)
+    re, im = np.zeros((nchan, n)), np.zeros((nchan, n))
+    for c, (_, _, p_one) in enumerate(cfg):
+        mag = np.where(rng.random(n) < p_one, 100.0, 10.0)
+        mag[rng.random(n) < 0.05] = 80.0  # exactly at the threshold: counts as a one
+        ph = rng.integers(0, 4, n) * (np.pi / 2)
+        re[c], im[c] = np.round(mag * np.cos(ph)), np.round(mag * np.sin(ph))
+    for cmax_all in (None, 7):  # one launch takes one max: per-channel maxima need their own launches
+        for c, (cmax, start, _) in enumerate(cfg):
+            cm = cmax if cmax_all is None else cmax_all
+            st = min(start, cm)
+            cnt = torch.tensor([st], dtype=torch.int32, device="cuda")
+            device.ones_zeros_confidence(_rows_dev(re[c:c + 1]), _rows_dev(im[c:c + 1]), cm, cnt)
+            assert int(cnt.item()) == L.orc_ones_zeros_confidence(np.ascontiguousarray(re[c]), np.ascontiguousarray(im[c]), n, cm, st)
+    # all channels in one launch
+    cnt = torch.tensor([min(s, 7) for _, s, _ in cfg], dtype=torch.int32, device="cuda")
+    device.ones_zeros_confidence(_rows_dev(re), _rows_dev(im), 7, cnt)
+    want = [L.orc_ones_zeros_confidence(np.ascontiguousarray(re[c]), np.ascontiguousarray(im[c]), n, 7, min(cfg[c][1], 7))
+            for c in range(nchan)]
+    assert cnt.cpu().tolist() == want
+
+
 # =============================================================================== DSP primitives (SURVEY 8f rank 3)
-
-def _rows_dev(a):
-    return torch.tensor(np.ascontiguousarray(a), device="cuda")
-
 
 @pytest.mark.parametrize("cw", [4, 16, 64])
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 15, 16, 17, 18, 33, 1000, 4099])

@@ -252,3 +252,17 @@ def test_dsp_primitives_vs_reference():
         assert np.max(np.abs(O.fft(z, O.MATH_SHARED) - b), initial=0.0) <= 1e-12 * max(1.0, np.abs(b).max(initial=0.0)) * np.log2(max(n, 2))
         if n >= 2:
             assert np.allclose(b, np.fft.fft(z), rtol=0, atol=1e-9)
+
+
+def test_ones_zeros_confidence_vs_reference():
+    """The receiver's ones/zeros CPU branch over the reference's own confidence_counter (increment(1) / decrement(1)
+    per sample, clamped at both rails) against the restatement: small maxima so that both rails are hit many times."""
+    R = O.ref()
+    rng = np.random.default_rng(99)
+    for n, cmax, start, p_one in ((0, 10, 5, 0.5), (1000, 10, 5, 0.5), (5000, 37, 0, 0.7), (5000, 37, 37, 0.3),
+                                  (20000, 500000, 250000, 0.9), (3000, 1, 0, 0.5)):
+        mag = np.where(rng.random(n) < p_one, 100.0, 10.0)
+        ph = rng.uniform(0, 2 * np.pi, n)
+        re, im = np.ascontiguousarray(mag * np.cos(ph)), np.ascontiguousarray(mag * np.sin(ph))
+        want = R.ref_ones_zeros_confidence(re, im, n, cmax, 0, cmax, start)
+        assert O.lib().orc_ones_zeros_confidence(re, im, n, cmax, start) == want
