@@ -177,6 +177,11 @@ int sdrx_normalize_dev(double *x, size_t n, size_t nchan, size_t pitch, double *
  * returns n / decimate_by; samples beyond the last written one keep their values. */
 int sdrx_fifth_order_decimate_dev(double *data, size_t n, size_t nchan, size_t pitch, size_t decimate_by, double *state6,
                                   void *stream);
+/* fifth_order_filter::decimate(BBP_Block*, size_t) (fifth_order_filter.cpp:28-63): rows of interleaved complex points
+ * (pitch in points, at least max(n_points, 3)); both rails, state12[12c..] = r_a..r_f, i_a..i_f; n_points shrinks to
+ * dst + 1 after every pass like block->n_points, the final value goes to *n_points_out (host). */
+int sdrx_fifth_order_decimate_block_dev(double *iq, size_t n_points, size_t nchan, size_t pitch, size_t decimate_by,
+                                        double *state12, size_t *n_points_out, void *stream);
 /* fft (FFT.cpp:7-28): in-place radix-2 transforms of nchan rows of n complex doubles (pitch in complex elements),
  * n a power of two <= SDRX_FFT_MAX; twiddles from sdrx_math.h's sincos (<= 1e-12 of the libm build). */
 #define SDRX_FFT_MAX 4096

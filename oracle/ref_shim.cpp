@@ -279,6 +279,16 @@ double ref_normalize(double *block, size_t n, double prev_max) { return normaliz
 void *ref_fifth_new() { return new fifth_order_filter(); }
 void ref_fifth_free(void *h) { delete (fifth_order_filter *)h; }
 size_t ref_fifth_decimate(void *h, double *data, size_t n, size_t by) { return ((fifth_order_filter *)h)->decimate(data, n, by); }
+// BBP_Block overload: the block holds `cap` points, of which n_points are valid; returns block->n_points
+size_t ref_fifth_decimate_block(void *h, double *iq, size_t cap, size_t n_points, size_t by)
+{
+    BBP_Block blk(cap);
+    for (size_t i = 0; i < cap; i++) blk.points[i] = Complex(iq[2 * i], iq[2 * i + 1]);
+    blk.n_points = n_points;
+    ((fifth_order_filter *)h)->decimate(&blk, by);
+    for (size_t i = 0; i < cap; i++) iq[2 * i] = blk.points[i].real(), iq[2 * i + 1] = blk.points[i].imag();
+    return blk.n_points;
+}
 void ref_fft(double *iq, size_t n)
 {
     Complex_Array a(n);

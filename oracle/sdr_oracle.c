@@ -987,3 +987,29 @@ static void fft_rec(double *x, size_t N, int math_mode)
 }
 
 void orc_fft(double *iq, size_t n, int math_mode) { fft_rec(iq, n, math_mode); }
+
+/* fifth_order_filter::decimate(BBP_Block*, size_t) (fifth_order_filter.cpp:28-63): interleaved complex points,
+ * state12 = r_a..r_f, i_a..i_f; returns block->n_points */
+size_t orc_fifth_order_decimate_block(double *iq, size_t n_points, size_t decimate_by, double *s)
+{
+    const double a = 1, b = 5, c = 10, d = 11;
+    double *r = s, *q = s + 6;
+    for (size_t dec = 2; dec <= decimate_by; dec *= 2) {
+        iq[0] = ((a * (r[0] + r[5])) + ((r[1] + r[4]) * b) + ((r[2] + r[3]) * c)) / d;
+        iq[1] = ((a * (q[0] + q[5])) + ((q[1] + q[4]) * b) + ((q[2] + q[3]) * c)) / d;
+        size_t dst = 2;
+        for (size_t i = 2; i < n_points; i += 2) {
+            dst = i / 2;
+            r[0] = r[2], r[1] = r[3], r[2] = r[4], r[3] = r[5];
+            r[4] = iq[2 * (i - 2)];
+            r[5] = iq[2 * i];
+            iq[2 * dst] = ((a * (r[0] + r[5])) + ((r[1] + r[4]) * b) + ((r[2] + r[3]) * c)) / d;
+            q[0] = q[2], q[1] = q[3], q[2] = q[4], q[3] = q[5];
+            q[4] = iq[2 * (i - 2) + 1];
+            q[5] = iq[2 * i + 1];
+            iq[2 * dst + 1] = ((a * (q[0] + q[5])) + ((q[1] + q[4]) * b) + ((q[2] + q[3]) * c)) / d;
+        }
+        n_points = dst + 1;
+    }
+    return n_points;
+}

@@ -32,6 +32,7 @@ void orc_notch(double *block, size_t n, const double *coef5, double *state4);   
 void orc_integrate(double *array, size_t n, double tStep);                       /* FirstOrderDigitalIntegration.cpp:12-18 */
 double orc_normalize(double *block, size_t n, double prev_max);                  /* Normalize.cpp:7-22 */
 size_t orc_fifth_order_decimate(double *data, size_t n, size_t decimate_by, double *state6); /* fifth_order_filter.cpp:65-88; state = r_a..r_f */
+size_t orc_fifth_order_decimate_block(double *iq, size_t n_points, size_t decimate_by, double *state12); /* :28-63 */
 void orc_fft(double *iq, size_t n, int math_mode);                               /* FFT.cpp:7-28, n a power of two, interleaved complex */
 
 #endif

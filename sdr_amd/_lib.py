@@ -70,6 +70,7 @@ SIGNATURES = {
     "sdrx_notch_design": (None, [C.c_double, C.c_double, _vp]),
     "sdrx_normalize_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp, _vp]),
     "sdrx_fifth_order_decimate_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, _vp]),
+    "sdrx_fifth_order_decimate_block_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, C.POINTER(C.c_size_t), _vp]),
     "sdrx_fft_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp]),
     "sdrx_psk_state_init_bpsk": (None, [C.POINTER(PskState), C.c_uint64, _sz]),
     "sdrx_psk_state_init_qpsk": (None, [C.POINTER(PskState), _vp, _sz]),

@@ -197,12 +197,13 @@ struct Pair {
     double e, f;
 };
 
+template <int STRIDE>
 __device__ __forceinline__ Pair fifth_pair(const double *d, long j, const double (&s)[6], double d0n)
 {
     if (j == -1) return {s[2], s[3]};
     if (j == 0) return {s[4], s[5]};
-    if (j == 1) return {d0n, d[2]};
-    return {d[2 * j - 2], d[2 * j]};
+    if (j == 1) return {d0n, d[2 * STRIDE]};
+    return {d[(2 * j - 2) * STRIDE], d[2 * j * STRIDE]};
 }
 
 __device__ __forceinline__ double fifth_out(Pair ab, Pair cd, Pair ef)
@@ -211,34 +212,46 @@ __device__ __forceinline__ double fifth_out(Pair ab, Pair cd, Pair ef)
     return ((a * (ab.e + ef.f)) + ((ab.f + ef.e) * b) + ((cd.e + cd.f) * c)) / d;
 }
 
+// BLOCK = false: the double* overload (one rail, every pass over the same n).  BLOCK = true: the BBP_Block
+// overload (:28-63): the real and the imaginary rail of interleaved complex points (one workgroup each, its own six
+// state doubles), and n_points shrinks to dst + 1 after every pass (3 if the pass had no iteration: the
+// reference's `dst = 2` start value).
+template <bool BLOCK>
 __global__ __launch_bounds__(256) void fifth_kernel(double *data, size_t n, size_t pitch, size_t by, double *state)
 {
-    const size_t c = blockIdx.x;
-    double *d = data + c * pitch;
+    constexpr int STRIDE = BLOCK ? 2 : 1;
+    const size_t c = BLOCK ? blockIdx.x >> 1 : blockIdx.x, rail = BLOCK ? blockIdx.x & 1 : 0;
+    double *d = data + c * pitch * STRIDE + rail;
+    double *sp = state + c * (6 * STRIDE) + rail * 6;
     double s[6];
-    for (int j = 0; j < 6; j++) s[j] = state[c * 6 + j];
-    const long K = (long)((n - 1) / 2); // iterations i = 2k < n, k = 1..K
+    for (int j = 0; j < 6; j++) s[j] = sp[j];
+    size_t np = n;
     for (size_t dec = 2; dec <= by; dec *= 2) {
+        const long K = (long)((np - 1) / 2); // iterations i = 2k < np, k = 1..K
         const double d0n = fifth_out({s[0], s[1]}, {s[2], s[3]}, {s[4], s[5]});
         double ns[6] = {s[0], s[1], s[2], s[3], s[4], s[5]};
         if (K >= 1) { // the window of the last iteration, read before anything is overwritten
-            Pair p0 = fifth_pair(d, K - 2, s, d0n), p1 = fifth_pair(d, K - 1, s, d0n), p2 = fifth_pair(d, K, s, d0n);
+            Pair p0 = fifth_pair<STRIDE>(d, K - 2, s, d0n), p1 = fifth_pair<STRIDE>(d, K - 1, s, d0n),
+                 p2 = fifth_pair<STRIDE>(d, K, s, d0n);
             ns[0] = p0.e, ns[1] = p0.f, ns[2] = p1.e, ns[3] = p1.f, ns[4] = p2.e, ns[5] = p2.f;
         }
         __syncthreads();
         for (long k0 = 1; k0 <= K; k0 += 256) {
             long k = k0 + threadIdx.x;
             double out = 0;
-            if (k <= K) out = fifth_out(fifth_pair(d, k - 2, s, d0n), fifth_pair(d, k - 1, s, d0n), fifth_pair(d, k, s, d0n));
+            if (k <= K)
+                out = fifth_out(fifth_pair<STRIDE>(d, k - 2, s, d0n), fifth_pair<STRIDE>(d, k - 1, s, d0n),
+                                fifth_pair<STRIDE>(d, k, s, d0n));
             __syncthreads();
-            if (k <= K) d[k] = out;
+            if (k <= K) d[k * STRIDE] = out;
         }
         if (threadIdx.x == 0) d[0] = d0n;
         for (int j = 0; j < 6; j++) s[j] = ns[j];
+        if (BLOCK) np = (size_t)(K >= 1 ? K : 2) + 1;
         __syncthreads(); // the next pass reads what this one wrote
     }
     if (threadIdx.x == 0)
-        for (int j = 0; j < 6; j++) state[c * 6 + j] = s[j];
+        for (int j = 0; j < 6; j++) sp[j] = s[j];
 }
 
 // ---- fft (FFT.cpp:7-28): recursive radix-2 DIT == bit-reversal + log2 N butterfly stages with the
@@ -448,7 +461,35 @@ extern "C" int sdrx_fifth_order_decimate_dev(double *data, size_t n, size_t ncha
         return SDRX_EINVAL;
     }
     if (decimate_by < 2) return SDRX_OK; // no pass runs (fifth_order_filter.cpp:70)
-    fifth_kernel<<<(unsigned)nchan, 256, 0, (hipStream_t)stream>>>(data, n, pitch, decimate_by, state6);
+    fifth_kernel<false><<<(unsigned)nchan, 256, 0, (hipStream_t)stream>>>(data, n, pitch, decimate_by, state6);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+extern "C" int sdrx_fifth_order_decimate_block_dev(double *iq, size_t n_points, size_t nchan, size_t pitch, size_t decimate_by,
+                                                   double *state12, size_t *n_points_out, void *stream)
+{
+    // n_points after the passes (host arithmetic: fifth_order_filter.cpp:31-62)
+    size_t np = n_points, most = n_points;
+    for (size_t dec = 2; dec <= decimate_by && n_points; dec *= 2) {
+        size_t K = (np - 1) / 2;
+        np = (K >= 1 ? K : 2) + 1;
+        if (np > most) most = np;
+    }
+    if (n_points_out) *n_points_out = np;
+    int r = check_rows(iq, n_points, nchan, pitch, "sdrx_fifth_order_decimate_block_dev");
+    if (r) return r < 0 ? r : SDRX_OK;
+    if (!state12) {
+        set_error("sdrx_fifth_order_decimate_block_dev: null state");
+        return SDRX_EINVAL;
+    }
+    if (pitch < most) { // a pass without an iteration leaves n_points = 3: the next pass reads point 2
+        set_error("sdrx_fifth_order_decimate_block_dev: rows must hold %zu points", most);
+        return SDRX_EINVAL;
+    }
+    if (decimate_by < 2) return SDRX_OK;
+    if (nchan > 0x3fffffffULL) return SDRX_EUNSUPPORTED;
+    fifth_kernel<true><<<(unsigned)(2 * nchan), 256, 0, (hipStream_t)stream>>>(iq, n_points, pitch, decimate_by, state12);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }

@@ -231,6 +231,18 @@ def fifth_order_decimate(x, by, state):
     return n // int(by)
 
 
+def fifth_order_decimate_block(z, n_points, by, state):
+    """fifth_order_filter::decimate(BBP_Block*) over every row of z (complex128, (nchan, capacity)) of which n_points
+    are valid; state: (nchan, 12) float64 device tensor.  Returns the block's n_points afterwards."""
+    assert z.dtype == torch.complex128 and z.dim() == 2 and z.is_contiguous()
+    nchan, cap = z.shape
+    assert state.dtype == torch.float64 and state.is_contiguous() and state.numel() == nchan * 12
+    out = C.c_size_t(0)
+    _lib.check(_lib.lib().sdrx_fifth_order_decimate_block_dev(_ptr(z), int(n_points), nchan, cap, int(by), _ptr(state),
+                                                              C.byref(out), _stream()), "sdrx_fifth_order_decimate_block_dev")
+    return int(out.value)
+
+
 def fft(z):
     """fft() over every row of z (complex128, (nchan, n), n a power of two <= FFT_MAX), in place."""
     assert z.dtype == torch.complex128 and z.dim() == 2 and z.is_contiguous()

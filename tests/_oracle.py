@@ -99,6 +99,8 @@ def lib():
     L.orc_normalize.restype = C.c_double
     L.orc_fifth_order_decimate.argtypes = [_f64, _sz, _sz, _f64]
     L.orc_fifth_order_decimate.restype = _sz
+    L.orc_fifth_order_decimate_block.argtypes = [_f64, _sz, _sz, _f64]
+    L.orc_fifth_order_decimate_block.restype = _sz
     L.orc_fft.argtypes = [_f64, _sz, C.c_int]
     L.orc_fft.restype = None
     L.orc_am_modulate.argtypes = [_u8, _sz, _f64, _sz]
@@ -370,6 +372,13 @@ def fifth_order_decimate(x, by, state):
     return y, r
 
 
+def fifth_order_decimate_block(z, n_points, by, state):
+    """z: complex128[capacity]; state: float64[12], updated; returns (array afterwards, n_points afterwards)"""
+    y = np.array(z, dtype=np.complex128)
+    r = lib().orc_fifth_order_decimate_block(y.view(np.float64), n_points, by, state)
+    return y, r
+
+
 def fft(iq, math_mode=MATH_SHARED):
     """iq: complex128[n], n a power of two"""
     y = np.array(iq, dtype=np.complex128)
@@ -405,6 +414,8 @@ def ref():
     R.ref_fifth_free.argtypes = [C.c_void_p]
     R.ref_fifth_decimate.argtypes = [C.c_void_p, _f64, _sz, _sz]
     R.ref_fifth_decimate.restype = _sz
+    R.ref_fifth_decimate_block.argtypes = [C.c_void_p, _f64, _sz, _sz, _sz]
+    R.ref_fifth_decimate_block.restype = _sz
     R.ref_fft.argtypes = [_f64, _sz]
     R.ref_fir_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
     R.ref_fir_new.restype = C.c_void_p

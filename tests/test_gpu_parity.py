@@ -566,6 +566,27 @@ def test_dsp_fifth_order_decimate_bit_exact(n, by):
         assert np.array_equal(d_st.cpu().numpy(), st)
 
 
+@pytest.mark.parametrize("n,by", [(1, 2), (2, 4), (3, 2), (5, 2), (7, 16), (64, 2), (513, 2), (515, 4), (1000, 8), (5000, 4),
+                                  (40, 1)])
+def test_dsp_fifth_order_block_overload_bit_exact(n, by):
+    """fifth_order_filter::decimate(BBP_Block*): complex points, both rails, n_points shrinking pass by pass, state
+    carried across two calls; whole rows, the twelve state doubles and the returned n_points equal the oracle's."""
+    rng = np.random.default_rng(n * 32 + by)
+    nchan, cap = 5, max(n, 3) + 11
+    st = np.zeros((nchan, 12))
+    d_st = torch.zeros(nchan, 12, dtype=torch.float64, device="cuda")
+    for call in range(2):
+        z = rng.normal(0, 10, (nchan, cap)) + 1j * rng.normal(0, 10, (nchan, cap))
+        zd = torch.tensor(z, device="cuda")
+        r = device.fifth_order_decimate_block(zd, n, by, d_st)
+        got = zd.cpu().numpy()
+        for c in range(nchan):
+            want, rw = O.fifth_order_decimate_block(z[c], n, by, st[c])
+            assert r == rw, (r, rw)
+            assert np.array_equal(got[c], want), (call, c)
+        assert np.array_equal(d_st.cpu().numpy(), st)
+
+
 @pytest.mark.parametrize("n", [1, 2, 4, 8, 64, 512, 1024, 4096])
 def test_dsp_fft(n):
     """fft(): bit-identical to the oracle in shared-math mode (same butterflies, same twiddle arithmetic), within

@@ -266,3 +266,20 @@ def test_ones_zeros_confidence_vs_reference():
         re, im = np.ascontiguousarray(mag * np.cos(ph)), np.ascontiguousarray(mag * np.sin(ph))
         want = R.ref_ones_zeros_confidence(re, im, n, cmax, 0, cmax, start)
         assert O.lib().orc_ones_zeros_confidence(re, im, n, cmax, start) == want
+
+
+def test_fifth_order_block_overload_vs_reference():
+    """fifth_order_filter::decimate(BBP_Block*): both rails, n_points shrinking pass by pass (3 after a pass without
+    an iteration), state carried over several blocks: bit for bit against the reference's class."""
+    R = O.ref()
+    rng = np.random.default_rng(5)
+    h = R.ref_fifth_new()
+    st = np.zeros(12)
+    cap = 1200
+    for n, by in ((64, 2), (1, 2), (2, 4), (3, 2), (129, 4), (1000, 8), (5, 2), (40, 1), (7, 16)):
+        z = rng.normal(0, 10, cap) + 1j * rng.normal(0, 10, cap)
+        b = z.copy()
+        r_ref = R.ref_fifth_decimate_block(h, b.view(np.float64), cap, n, by)
+        y, r = O.fifth_order_decimate_block(z, n, by, st)
+        assert r == r_ref and np.array_equal(y, b), (n, by)
+    R.ref_fifth_free(h)
