@@ -136,6 +136,20 @@ int sdrx_fm_demod_dev(const double *re, const double *w1, const double *w2, uint
  * (prev_index + n) / downsample pcm samples per channel (the caller tracks prev_index = (prev_index + n) % downsample). */
 int sdrx_rtlfm_dev(const uint8_t *iq_u8, size_t n, size_t nchan, size_t in_pitch, int downsample, int rotate90,
                    const int32_t *state_in, int32_t *state_out, int16_t *pcm, size_t out_pitch, void *stream);
+/* The rest of rtl_fm's full_demod (rtl_fm.c:730-780) around that chain, for downsample_passes == 0 and fm_demod:
+ * power squelch between low_pass and fm_demod (rms, :650-667: below squelch_level the call's lowpassed[] is zeroed and
+ * squelch_hits counts up, else it is reset), then on the pcm row low_pass_simple (:325-339, post_downsample > 1),
+ * deemph_filter (:598-617, deemph_a > 0; rtl_fm.c:1221 computes deemph_a) and dc_block_filter (:619-632).
+ * post_state, 4 x int32 per channel, read and written: deemph avg (a function static in rtl_fm), dc_avg, squelch_hits,
+ * result_len (out: the number of pcm samples this call left).  work: nchan x 2 int64 of scratch (only for squelch_level
+ * != 0).  With post_downsample = s > 1, out_pitch must hold ceil(m / s) * s and ceil(m / s) + 2 samples (the reference's
+ * loop reads whole windows and writes one sample past its output), m = (prev_index + n) / downsample. */
+typedef struct sdrx_rtlfm_params {
+    int32_t downsample, rotate90, squelch_level, post_downsample, deemph_a, dc_block;
+} sdrx_rtlfm_params;
+int sdrx_rtlfm_full_dev(const sdrx_rtlfm_params *params, const uint8_t *iq_u8, size_t n, size_t nchan, size_t in_pitch,
+                        const int32_t *state_in, int32_t *state_out, int32_t *post_state, int64_t *work, int16_t *pcm,
+                        size_t out_pitch, void *stream);
 
 /* The bit-domain back end of the receive path: what RtlSdr_Receiver::deserializeData (rtlsdr_receiver.cpp:2197-2230)
  * does with PacketFramer<T>::deserialize (network/PacketFramer.h:424-513), RingBuffer<T> and crc8 (crc/crc8.cpp), on

@@ -277,8 +277,8 @@ void orc_fm_discriminator_i16(const int16_t *iq, size_t n, int16_t *pre, int16_t
  * low_pass (rtl_fm.c:303-323): boxcar sum of `downsample` samples, partial sum carried in now_r/now_j/prev_index,
  * stored back as int16; fm_demod (rtl_fm.c:518-546) with custom_atan == 0.  st = {now_r, now_j, prev_index, pre_r, pre_j}.
  * Returns the number of pcm samples written.  (rtl_fm.c needs librtlsdr and is not built here: parity unpinned.) */
-size_t orc_rtlfm_chain(const uint8_t *iq_u8, size_t n, int downsample, int rotate90, int32_t *st, int16_t *pcm,
-                       int math_mode)
+/* rtlsdr_callback's conversion + low_pass (rtl_fm.c:808-822, 303-323): returns lowpassed[] (malloc'd, 2*m int16) */
+static int16_t *rtlfm_lowpass_stage(const uint8_t *iq_u8, size_t n, int downsample, int rotate90, int32_t *st, size_t *m_out)
 {
     size_t len = 2 * n;
     uint8_t *buf = (uint8_t *)malloc(len ? len : 1);
@@ -304,16 +304,101 @@ size_t orc_rtlfm_chain(const uint8_t *iq_u8, size_t n, int downsample, int rotat
     st[0] = now_r;
     st[1] = now_j;
     st[2] = prev_index;
-    size_t m = i2 / 2;
+    free(buf);
+    *m_out = i2 / 2;
+    return lp;
+}
+
+size_t orc_rtlfm_chain(const uint8_t *iq_u8, size_t n, int downsample, int rotate90, int32_t *st, int16_t *pcm,
+                       int math_mode)
+{
+    size_t m;
+    int16_t *lp = rtlfm_lowpass_stage(iq_u8, n, downsample, rotate90, st, &m);
     if (m) { /* fm_demod: with lp_len == 0 the reference would read lp[-2]; it is never called that way */
         int16_t pre[2] = {(int16_t)st[3], (int16_t)st[4]};
         orc_fm_discriminator_i16(lp, m, pre, pcm, math_mode);
         st[3] = pre[0];
         st[4] = pre[1];
     }
-    free(buf);
     free(lp);
     return m;
+}
+
+/* rms (rtl_fm.c:650-667) */
+static int rtlfm_rms(const int16_t *samples, int len, int step)
+{
+    long p = 0, t = 0, s;
+    for (int i = 0; i < len; i += step) {
+        s = (long)samples[i];
+        t += s;
+        p += s * s;
+    }
+    double dc = (double)(t * step) / (double)len;
+    double err = t * 2 * dc - dc * dc * len;
+    double v = (p - err) / len;
+    double r = sqrt(v);
+    return r == r && r > -2147483648.0 ? (int)r : (-2147483647 - 1); /* (int)NaN on x86: INT_MIN */
+}
+
+/* full_demod (rtl_fm.c:730-780) on one callback's bytes, downsample_passes == 0, mode_demod == fm_demod:
+ * low_pass -> power squelch (rms, :650-667) -> fm_demod -> low_pass_simple (:325-339) -> deemph_filter (:598-617)
+ * -> dc_block_filter (:619-632).  post[4] = {deemph avg (a function static in rtl_fm), dc_avg, squelch_hits,
+ * result_len}; pcm is result[] (capacity cap, contents beyond the written part are read by low_pass_simple when
+ * result_len is not a multiple of the step, like the reference reads its buffer).  Returns result_len.
+ * PARITY UNPINNED: rtl_fm.c needs librtlsdr and its vendored copy does not compile (low_pass_real). */
+size_t orc_rtlfm_full(const uint8_t *iq_u8, size_t n, int downsample, int rotate90, int squelch_level, int post_downsample,
+                      int deemph_a, int dc_block, int32_t *st, int32_t *post, int16_t *pcm, size_t cap, int math_mode)
+{
+    size_t m;
+    int16_t *lp = rtlfm_lowpass_stage(iq_u8, n, downsample, rotate90, st, &m);
+    (void)cap;
+    if (squelch_level) {
+        int sr = rtlfm_rms(lp, (int)(2 * m), 1);
+        if (sr < squelch_level) {
+            post[2]++;
+            for (size_t i = 0; i < 2 * m; i++) lp[i] = 0;
+        } else {
+            post[2] = 0;
+        }
+    }
+    if (m) {
+        int16_t pre[2] = {(int16_t)st[3], (int16_t)st[4]};
+        orc_fm_discriminator_i16(lp, m, pre, pcm, math_mode);
+        st[3] = pre[0];
+        st[4] = pre[1];
+    }
+    free(lp);
+    int result_len = (int)m;
+    if (post_downsample > 1) { /* low_pass_simple */
+        int i, i2, sum, step = post_downsample;
+        for (i = 0; i < result_len; i += step) {
+            sum = 0;
+            for (i2 = 0; i2 < step; i2++) sum += (int)pcm[i + i2];
+            pcm[i / step] = (int16_t)(sum);
+        }
+        pcm[i / step + 1] = pcm[i / step];
+        result_len = result_len / step;
+    }
+    if (deemph_a > 0) { /* deemph_filter */
+        int avg = post[0];
+        for (int i = 0; i < result_len; i++) {
+            int d = pcm[i] - avg;
+            if (d > 0) avg += (d + deemph_a / 2) / deemph_a;
+            else avg += (d - deemph_a / 2) / deemph_a;
+            pcm[i] = (int16_t)avg;
+        }
+        post[0] = avg;
+    }
+    if (dc_block && result_len > 0) { /* dc_block_filter (divides by result_len) */
+        int64_t sum = 0;
+        for (int i = 0; i < result_len; i++) sum += pcm[i];
+        int avg = (int)(sum / result_len);
+        avg = (avg + post[1] * 9) / 10;
+        for (int i = 0; i < result_len; i++) pcm[i] = (int16_t)(pcm[i] - avg);
+        post[1] = avg;
+    }
+    post[3] = result_len;
+    return (size_t)result_len;
 }
 
 /* ---------------------------------------------------------------- Resample */

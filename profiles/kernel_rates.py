@@ -70,7 +70,12 @@ t = timed(lambda: fm.demod(raw, pcm))
 tot = nchan * nb
 rows.append({"kernel": "rtlfm int16 chain ds=10", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
              "algorithmic_GBps": 2.2 * tot / t / 1e9, "frac_of_8TBps": 2.2 * tot / t / 1e9 / PEAK})
-del raw, pcm
+fmf = device.RtlFmFull(nchan, 10, squelch_level=100, post_downsample=4, deemph_a=3, dc_block=True)
+pcmf = torch.zeros(nchan, nb // 10 + 8, dtype=torch.int16, device=dev)
+t = timed(lambda: fmf.demod(raw, pcmf))
+rows.append({"kernel": "rtlfm full_demod (squelch, /4, deemph, dc block) ds=10", "samples": tot, "ms": t * 1e3,
+             "Msamples_per_s": tot / t / 1e6, "algorithmic_GBps": 4.2 * tot / t / 1e9, "frac_of_8TBps": 4.2 * tot / t / 1e9 / PEAK})
+del raw, pcm, pcmf
 # bit-domain back end: 1024 channels x 2^18 bits, (a) dense framed packets, (b) noise with no header
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from signals import framed_bit_stream  # noqa: E402

@@ -31,6 +31,11 @@ class FirJob(C.Structure):
     ]
 
 
+class RtlFmParams(C.Structure):
+    _fields_ = [("downsample", C.c_int32), ("rotate90", C.c_int32), ("squelch_level", C.c_int32),
+                ("post_downsample", C.c_int32), ("deemph_a", C.c_int32), ("dc_block", C.c_int32)]
+
+
 class FrameEvent(C.Structure):
     """sdrx_frame_event"""
 
@@ -64,6 +69,7 @@ SIGNATURES = {
     "sdrx_ones_zeros_confidence_dev": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_int32, _vp, _vp]),
     "sdrx_fm_demod_dev": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "sdrx_rtlfm_dev": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, C.c_int, _vp, _vp, _vp, _sz, _vp]),
+    "sdrx_rtlfm_full_dev": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sdrx_deframe_dev": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _sz, _vp, _vp]),
     "sdrx_iir_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "sdrx_lowpass1_coef": (C.c_double, [C.c_double, C.c_double]),

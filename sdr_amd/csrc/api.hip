@@ -163,6 +163,14 @@ extern "C" int sdrx_rtlfm_dev(const uint8_t *iq_u8, size_t n, size_t nchan, size
                         (hipStream_t)stream);
 }
 
+extern "C" int sdrx_rtlfm_full_dev(const sdrx_rtlfm_params *params, const uint8_t *iq_u8, size_t n, size_t nchan,
+                                   size_t in_pitch, const int32_t *state_in, int32_t *state_out, int32_t *post_state,
+                                   int64_t *work, int16_t *pcm, size_t out_pitch, void *stream)
+{
+    return launch_rtlfm_full(params, iq_u8, n, nchan, in_pitch, state_in, state_out, post_state, work, pcm, out_pitch,
+                             (hipStream_t)stream);
+}
+
 extern "C" int sdrx_deframe_dev(const uint8_t *bits, size_t n, size_t nchan, size_t in_pitch, int crc_enable,
                                 sdrx_frame_event *events, uint8_t *payloads, size_t max_events, uint64_t *summary, void *stream)
 {

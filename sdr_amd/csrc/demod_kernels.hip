@@ -359,38 +359,99 @@ __device__ __forceinline__ void rtlfm_sum(const uint8_t *__restrict__ x, long lo
     }
 }
 
+// lowpassed[] pair number mm of a call (rtl_fm.c:303-323): samples [mm*ds - prev_index, (mm+1)*ds - prev_index) of
+// the call; pair 0 continues the carried partial sum; narrowed to int16 like lowpassed[] (rtl_fm.c:117,313-314)
+struct RtlfmCarry {
+    int now_r, now_j, prev_index;
+};
+__device__ __forceinline__ void rtlfm_lowpassed(const uint8_t *__restrict__ x, long long mm, int ds, int rotate90,
+                                                const RtlfmCarry &c, int &r, int &j)
+{
+    int sr = mm == 0 ? c.now_r : 0, sj = mm == 0 ? c.now_j : 0;
+    long long first = mm * ds - c.prev_index, last = first + ds;
+    rtlfm_sum(x, first < 0 ? 0 : first, last, rotate90, sr, sj);
+    r = (int)(int16_t)sr;
+    j = (int)(int16_t)sj;
+}
+
+// Power squelch, first half (rtl_fm.c:650-660): t = sum, p = sum of squares of the call's lowpassed[] values,
+// exact in 64-bit integers in any order.  acc[2 chan] += t, acc[2 chan + 1] += p (zeroed by the launcher).
+__global__ void __launch_bounds__(256) rtlfm_power_kernel(const uint8_t *__restrict__ iq, size_t n, size_t nchan,
+                                                          size_t in_pitch, int ds, int rotate90,
+                                                          const int32_t *__restrict__ st_in,
+                                                          unsigned long long *__restrict__ acc)
+{
+    const size_t chan = (size_t)blockIdx.z * 65535u + blockIdx.y;
+    if (chan >= nchan) return;
+    const uint8_t *x = iq + 2 * chan * in_pitch;
+    const int32_t *si = st_in + 5 * chan;
+    const RtlfmCarry c = {si[0], si[1], si[2]};
+    const long long m_total = ((long long)c.prev_index + (long long)n) / ds;
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long t = 0, p = 0;
+    if (m < m_total) {
+        int r, j;
+        rtlfm_lowpassed(x, m, ds, rotate90, c, r, j);
+        t = (long long)r + j;
+        p = (long long)r * r + (long long)j * j;
+    }
+    __shared__ long long red_t[4], red_p[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        t += __shfl_xor(t, off);
+        p += __shfl_xor(p, off);
+    }
+    if ((threadIdx.x & 63) == 0) red_t[threadIdx.x >> 6] = t, red_p[threadIdx.x >> 6] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t = red_t[0] + red_t[1] + red_t[2] + red_t[3];
+        p = red_p[0] + red_p[1] + red_p[2] + red_p[3];
+        if (t | p) {
+            atomicAdd(acc + 2 * chan, (unsigned long long)t);
+            atomicAdd(acc + 2 * chan + 1, (unsigned long long)p);
+        }
+    }
+}
+
+// second half (rtl_fm.c:661-667 and full_demod :752-761): sr = (int)sqrt((p - err) / len) < squelch_level, evaluated
+// as !(v >= sq_thr) with sq_thr the smallest double whose rounded square root reaches the level (NaN / negative v
+// convert to INT_MIN on the CPU: squelched)
+__device__ __forceinline__ bool rtlfm_squelched(const unsigned long long *acc, size_t chan, long long m_total, double sq_thr)
+{
+    const long long t = (long long)acc[2 * chan], p = (long long)acc[2 * chan + 1];
+    const double len = (double)(2 * m_total);
+    const double dc = (double)t / len;
+    const double err = (double)(t * 2) * dc - dc * dc * len;
+    const double v = ((double)p - err) / len;
+    return !(v >= sq_thr);
+}
+
 __global__ void __launch_bounds__(256) rtlfm_kernel(const uint8_t *__restrict__ iq, size_t n, size_t nchan,
                                                     size_t in_pitch, int ds,
                                                     int rotate90, const int32_t *__restrict__ st_in,
                                                     int32_t *__restrict__ st_out, int16_t *__restrict__ pcm,
-                                                    size_t out_pitch)
+                                                    size_t out_pitch, const unsigned long long *__restrict__ acc,
+                                                    double sq_thr, int32_t *__restrict__ post_state)
 {
     __shared__ int xr[256], xj[256];
     const size_t chan = (size_t)blockIdx.z * 65535u + blockIdx.y; // grid.y is limited to 65535
     if (chan >= nchan) return;                                     // a whole workgroup
     const uint8_t *x = iq + 2 * chan * in_pitch;
     const int32_t *si = st_in + 5 * chan;
-    const int now_r = si[0], now_j = si[1], prev_index = si[2];
-    const long long m_total = ((long long)prev_index + (long long)n) / ds; // outputs of this call
+    const RtlfmCarry c = {si[0], si[1], si[2]};
+    const long long m_total = ((long long)c.prev_index + (long long)n) / ds; // outputs of this call
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    // output m covers samples [m*ds - prev_index, (m+1)*ds - prev_index); output 0 also the carried partial sum
-    auto lowpassed = [&](long long mm, int &r, int &j) {
-        int sr = mm == 0 ? now_r : 0, sj = mm == 0 ? now_j : 0;
-        long long first = mm * ds - prev_index, last = first + ds;
-        rtlfm_sum(x, first < 0 ? 0 : first, last, rotate90, sr, sj);
-        r = (int)(int16_t)sr; // lowpassed[] is int16_t (rtl_fm.c:117,313-314)
-        j = (int)(int16_t)sj;
-    };
+    const bool mute = acc != nullptr && rtlfm_squelched(acc, chan, m_total, sq_thr); // lowpassed[] zeroed (:755-757)
     int ar = 0, aj = 0;
-    if (m < m_total) lowpassed(m, ar, aj);
+    if (m < m_total && !mute) rtlfm_lowpassed(x, m, ds, rotate90, c, ar, aj);
     xr[threadIdx.x] = ar;
     xj[threadIdx.x] = aj;
     __syncthreads();
     if (m < m_total) {
-        int br, bj;
+        int br = 0, bj = 0;
         if (threadIdx.x > 0) { br = xr[threadIdx.x - 1]; bj = xj[threadIdx.x - 1]; }
         else if (m == 0) { br = si[3]; bj = si[4]; }              // pre_r, pre_j (rtl_fm.c:523)
-        else lowpassed(m - 1, br, bj);                             // first thread of a later workgroup
+        else if (!mute) rtlfm_lowpassed(x, m - 1, ds, rotate90, c, br, bj); // first thread of a later workgroup
         bj = -bj;                                                  // multiply(a, conj b): rtl_fm.c:422-426,432
         const int cr = ar * br - aj * bj, cj = aj * br + ar * bj;
         const double angle = sdrx_atan2((double)cj, (double)cr);
@@ -398,14 +459,129 @@ __global__ void __launch_bounds__(256) rtlfm_kernel(const uint8_t *__restrict__ 
         if (m == m_total - 1) { st_out[5 * chan + 3] = ar; st_out[5 * chan + 4] = aj; } // rtl_fm.c:543-544
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { // the samples after the last whole window stay in the partial sum
-        int sr = m_total == 0 ? now_r : 0, sj = m_total == 0 ? now_j : 0;
-        long long first = m_total * ds - prev_index;
+        int sr = m_total == 0 ? c.now_r : 0, sj = m_total == 0 ? c.now_j : 0;
+        long long first = m_total * ds - c.prev_index;
         rtlfm_sum(x, first < 0 ? 0 : first, (long long)n, rotate90, sr, sj);
         st_out[5 * chan + 0] = sr;
         st_out[5 * chan + 1] = sj;
-        st_out[5 * chan + 2] = (int32_t)(((long long)prev_index + (long long)n) % ds);
+        st_out[5 * chan + 2] = (int32_t)(((long long)c.prev_index + (long long)n) % ds);
         if (m_total == 0) { st_out[5 * chan + 3] = si[3]; st_out[5 * chan + 4] = si[4]; }
+        if (acc != nullptr) post_state[4 * chan + 2] = mute ? post_state[4 * chan + 2] + 1 : 0; // squelch_hits (:754,:759)
     }
+}
+
+// After fm_demod (full_demod, rtl_fm.c:768-775), one workgroup per channel, in place on the channel's pcm row:
+//   low_pass_simple (:325-339): result[k] = (int16)(sum of `step` results), windows over ceil(len / step) * step
+//     values (the reference does not stop at len either), then result[W + 1] = result[W]; result_len = len / step;
+//   deemph_filter (:598-617): avg += (d +- a/2) / a, serial, one lane (avg is a function static in rtl_fm: per channel
+//     here, post_state[4 chan]);
+//   dc_block_filter (:619-632): 64-bit sum, avg = (sum / len + 9 dc_avg) / 10, subtracted from every result.
+constexpr int DEEMPH_CHUNK = 4096;
+
+__global__ void __launch_bounds__(256) rtlfm_post_kernel(int16_t *__restrict__ pcm_all, size_t out_pitch, size_t n, int ds,
+                                                         int step, int deemph_a, int dc_block,
+                                                         const int32_t *__restrict__ st_in, int32_t *__restrict__ post_state)
+{
+    __shared__ long long red[4];
+    __shared__ __align__(16) int16_t stage[DEEMPH_CHUNK];
+    const size_t chan = blockIdx.x;
+    const unsigned tid = threadIdx.x;
+    int16_t *res = pcm_all + chan * out_pitch;
+    int32_t *ps = post_state + 4 * chan;
+    int len = (int)(((long long)st_in[5 * chan + 2] + (long long)n) / ds); // result_len after fm_demod
+    if (step > 1) {
+        const int W = (len + step - 1) / step;
+        for (int k0 = 0; k0 < W; k0 += 256) { // output k lands below every value a later window reads
+            const int k = k0 + (int)tid;
+            int sum = 0;
+            if (k < W)
+                for (int i2 = 0; i2 < step; i2++) sum += (int)res[(size_t)k * step + i2];
+            __syncthreads();
+            if (k < W) res[k] = (int16_t)sum;
+        }
+        __syncthreads();
+        if (tid == 0) res[W + 1] = res[W];
+        len = len / step;
+        __syncthreads();
+    }
+    if (deemph_a > 0) { // the workgroup moves the row through LDS in chunks; one lane runs the recurrence there
+        int avg = ps[0];
+        const int half = deemph_a / 2;
+        // q = (u * magic) >> 32 == u / a exactly for u < 2^20, a < 2^11 (sdrx_internal.h: magic_u32)
+        const unsigned magic = deemph_a < 2048 ? (unsigned)((0x100000000ULL + (unsigned)deemph_a - 1) / (unsigned)deemph_a) : 0u;
+        for (int i0 = 0; i0 < len; i0 += DEEMPH_CHUNK) {
+            const int cn = len - i0 < DEEMPH_CHUNK ? len - i0 : DEEMPH_CHUNK;
+            for (int i = (int)tid; i < cn; i += 256) stage[i] = res[i0 + i];
+            __syncthreads();
+            if (tid == 0) {
+                // 8 samples per 16-byte LDS access; the next block is read before the current block's chain runs
+                uint4 *blk = reinterpret_cast<uint4 *>(stage);
+                const int nblk = (cn + 7) / 8;
+                uint4 nxt = blk[0];
+                for (int b = 0; b < nblk; b++) {
+                    uint4 cur = nxt;
+                    if (b + 1 < nblk) nxt = blk[b + 1];
+                    unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+                    const int lim = cn - 8 * b < 8 ? cn - 8 * b : 8;
+                    // avg never leaves the range of the int16 inputs once inside it (|step| <= |d|), so there
+                    // |d +- a/2| < 2^20 and the magic multiply is the exact quotient; otherwise divide
+                    if (magic && (unsigned)(avg + 32768) < 65536u) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            if (k < lim) {
+                                const int v = (int)(int16_t)(w[k >> 1] >> (16 * (k & 1)));
+                                const int d = v - avg; // both signs' quotients side by side: a shorter dependent chain
+                                const int qp = (int)__umulhi((unsigned)(d + half), magic);  // d > 0: (d + a/2) / a
+                                const int qn = (int)__umulhi((unsigned)(half - d), magic);  // d <= 0: -((a/2 - d) / a), C division
+                                avg += d > 0 ? qp : -qn;                                     // truncates towards zero
+                                w[k >> 1] = (w[k >> 1] & ~(0xffffu << (16 * (k & 1)))) | (((unsigned)avg & 0xffffu) << (16 * (k & 1)));
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) { // (unrolled: w[] must stay in registers)
+                            if (k < lim) {
+                                const int v = (int)(int16_t)(w[k >> 1] >> (16 * (k & 1)));
+                                const int d = v - avg;
+                                avg += (d > 0 ? d + half : d - half) / deemph_a;
+                                w[k >> 1] = (w[k >> 1] & ~(0xffffu << (16 * (k & 1)))) | (((unsigned)avg & 0xffffu) << (16 * (k & 1)));
+                            }
+                        }
+                    }
+                    blk[b] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+            __syncthreads();
+            for (int i = (int)tid; i < cn; i += 256) res[i0 + i] = stage[i];
+            __syncthreads();
+        }
+        if (tid == 0) ps[0] = avg;
+        __syncthreads();
+    }
+    if (dc_block && len > 0) {
+        long long sum = 0;
+        for (int i = (int)tid; i < len; i += 256) sum += res[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if ((tid & 63) == 0) red[tid >> 6] = sum;
+        __syncthreads();
+        sum = red[0] + red[1] + red[2] + red[3];
+        int avg = (int)(sum / len);
+        avg = (avg + ps[1] * 9) / 10;
+        __syncthreads(); // every thread has read ps[1]
+        for (int i = (int)tid; i < len; i += 256) res[i] = (int16_t)((int)res[i] - avg);
+        if (tid == 0) ps[1] = avg;
+    }
+    if (tid == 0) ps[3] = len;
+}
+
+static int rtlfm_grid(size_t n, size_t nchan, int ds, dim3 &grid)
+{
+    const size_t blocks = (n / (size_t)ds + 1 + 255) / 256; // prev_index < ds adds at most one output
+    if (blocks > 0x7fffffffULL || nchan > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
+    const unsigned gy = nchan < 65535 ? (unsigned)nchan : 65535u, gz = (unsigned)((nchan + 65534) / 65535);
+    grid = dim3((unsigned)blocks, gy, gz);
+    return SDRX_OK;
 }
 
 int launch_rtlfm(const uint8_t *iq, size_t n, size_t nchan, size_t in_pitch, int ds, int rotate90,
@@ -416,11 +592,59 @@ int launch_rtlfm(const uint8_t *iq, size_t n, size_t nchan, size_t in_pitch, int
         return SDRX_EINVAL;
     }
     if (nchan == 0) return SDRX_OK;
-    const size_t blocks = (n / (size_t)ds + 1 + 255) / 256; // prev_index < ds adds at most one output
-    if (blocks > 0x7fffffffULL || nchan > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
-    const unsigned gy = nchan < 65535 ? (unsigned)nchan : 65535u, gz = (unsigned)((nchan + 65534) / 65535);
-    hipLaunchKernelGGL(rtlfm_kernel, dim3((unsigned)blocks, gy, gz), dim3(256), 0, s, iq, n, nchan, in_pitch, ds,
-                       rotate90, st_in, st_out, pcm, out_pitch);
+    dim3 grid;
+    int rc = rtlfm_grid(n, nchan, ds, grid);
+    if (rc != SDRX_OK) return rc;
+    hipLaunchKernelGGL(rtlfm_kernel, grid, dim3(256), 0, s, iq, n, nchan, in_pitch, ds, rotate90, st_in, st_out, pcm,
+                       out_pitch, (const unsigned long long *)nullptr, 0.0, (int32_t *)nullptr);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
+// smallest double v with (int)sqrt(v) >= level, i.e. sqrt_rn(v) >= level (IEEE sqrt is monotone)
+static double squelch_threshold(int level)
+{
+    double v = (double)level * (double)level;
+    while (v > 0.0 && sqrt(nextafter(v, 0.0)) >= (double)level) v = nextafter(v, 0.0);
+    return v;
+}
+
+int launch_rtlfm_full(const sdrx_rtlfm_params *p, const uint8_t *iq, size_t n, size_t nchan, size_t in_pitch,
+                      const int32_t *st_in, int32_t *st_out, int32_t *post_state, int64_t *work, int16_t *pcm,
+                      size_t out_pitch, hipStream_t s)
+{
+    if (!p || !iq || !st_in || !st_out || !pcm || !post_state || p->downsample < 1 || st_in == st_out || p->squelch_level < 0 ||
+        (p->squelch_level && !work)) {
+        set_error("sdrx_rtlfm_full_dev: bad argument");
+        return SDRX_EINVAL;
+    }
+    if (nchan == 0) return SDRX_OK;
+    const int ds = p->downsample, step = p->post_downsample;
+    if (step > 1) { // low_pass_simple reads whole windows and writes result[W + 1]
+        const size_t m_max = n / (size_t)ds + 1, W = (m_max + step - 1) / step;
+        if (out_pitch < W * step || out_pitch < W + 2) {
+            set_error("sdrx_rtlfm_full_dev: out_pitch %zu too small for post_downsample %d (needs %zu)", out_pitch, step,
+                      W * step > W + 2 ? W * step : W + 2);
+            return SDRX_EINVAL;
+        }
+    }
+    if (n / (size_t)ds + 1 > 0x3fffffffULL) return SDRX_EUNSUPPORTED;
+    dim3 grid;
+    int rc = rtlfm_grid(n, nchan, ds, grid);
+    if (rc != SDRX_OK) return rc;
+    const unsigned long long *acc = nullptr;
+    double thr = 0.0;
+    if (p->squelch_level) {
+        SDRX_HIP(hipMemsetAsync(work, 0, nchan * 2 * sizeof(int64_t), s));
+        hipLaunchKernelGGL(rtlfm_power_kernel, grid, dim3(256), 0, s, iq, n, nchan, in_pitch, ds, p->rotate90, st_in,
+                           (unsigned long long *)work);
+        acc = (const unsigned long long *)work;
+        thr = squelch_threshold(p->squelch_level);
+    }
+    hipLaunchKernelGGL(rtlfm_kernel, grid, dim3(256), 0, s, iq, n, nchan, in_pitch, ds, p->rotate90, st_in, st_out, pcm,
+                       out_pitch, acc, thr, post_state);
+    hipLaunchKernelGGL(rtlfm_post_kernel, dim3((unsigned)nchan), dim3(256), 0, s, pcm, out_pitch, n, ds, step, p->deemph_a,
+                       p->dc_block, st_in, post_state);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }

@@ -46,6 +46,10 @@ int launch_fm_demod(const double *re, const double *w1, const double *w2, uint8_
 int launch_rtlfm(const uint8_t *iq, size_t n, size_t nchan, size_t in_pitch, int ds, int rotate90,
                  const int32_t *st_in, int32_t *st_out, int16_t *pcm, size_t out_pitch, hipStream_t s);
 
+int launch_rtlfm_full(const sdrx_rtlfm_params *p, const uint8_t *iq, size_t n, size_t nchan, size_t in_pitch,
+                      const int32_t *st_in, int32_t *st_out, int32_t *post_state, int64_t *work, int16_t *pcm,
+                      size_t out_pitch, hipStream_t s);
+
 // framer_kernels.hip
 int launch_deframe(const uint8_t *bits, size_t n, size_t nchan, size_t in_pitch, int crc_enable, sdrx_frame_event *events,
                    uint8_t *payloads, size_t max_events, uint64_t *summary, hipStream_t s);

@@ -159,6 +159,31 @@ class RtlFm:
         return m
 
 
+class RtlFmFull(RtlFm):
+    """RtlFm plus the rest of rtl_fm's full_demod: power squelch, post_downsample (low_pass_simple), de-emphasis and
+    DC block (sdrx_rtlfm_full_dev).  post_state: (nchan, 4) int32 = deemph avg, dc_avg, squelch_hits, result_len."""
+
+    def __init__(self, nchan=1, downsample=10, rotate90=False, squelch_level=0, post_downsample=1, deemph_a=0,
+                 dc_block=False, device="cuda"):
+        super().__init__(nchan, downsample, rotate90, device)
+        self.params = _lib.RtlFmParams(int(downsample), int(bool(rotate90)), int(squelch_level), int(post_downsample),
+                                       int(deemph_a), int(bool(dc_block)))
+        self.post_state = torch.zeros(self.nchan, 4, dtype=torch.int32, device=device)
+        self.work = torch.zeros(self.nchan, 2, dtype=torch.int64, device=device)
+
+    def demod(self, raw, pcm):
+        """As RtlFm.demod; returns result_len (the same for every channel)."""
+        assert raw.dtype == torch.uint8 and raw.is_contiguous() and pcm.dtype == torch.int16 and pcm.is_contiguous()
+        n = raw.shape[1]
+        _lib.check(self.L.sdrx_rtlfm_full_dev(C.byref(self.params), _ptr(raw), n, self.nchan, n, _ptr(self.state[self.cur]),
+                                              _ptr(self.state[self.cur ^ 1]), _ptr(self.post_state), _ptr(self.work),
+                                              _ptr(pcm), pcm.shape[1], _stream()), "sdrx_rtlfm_full_dev")
+        self.cur ^= 1
+        m = (self.prev_index + n) // self.ds
+        self.prev_index = (self.prev_index + n) % self.ds
+        return m // self.params.post_downsample if self.params.post_downsample > 1 else m
+
+
 def deframe(bits, crc_enable=True, max_events=1024):
     """bits: (nchan, n) uint8 0/1 on the device.  Returns per channel a dict like the reference's loop would leave:
     events (pos, kind, len, crc as numpy arrays), payload (k, 250), counts; see sdrx_deframe_dev."""

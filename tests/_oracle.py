@@ -123,6 +123,8 @@ def lib():
     L.orc_fm_discriminator_i16.restype = None
     L.orc_rtlfm_chain.argtypes = [_u8, _sz, C.c_int, C.c_int, _i32, _i16, C.c_int]
     L.orc_rtlfm_chain.restype = _sz
+    L.orc_rtlfm_full.argtypes = [_u8, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32, _i32, _i16, _sz, C.c_int]
+    L.orc_rtlfm_full.restype = _sz
     L.orc_decimate.argtypes = [_f64, _sz, _sz]
     L.orc_decimate.restype = _sz
     L.orc_upsample_fill_w_zeros.argtypes = [_f64, _sz, _f64, _sz, C.c_double]
@@ -245,6 +247,15 @@ def rtlfm_chain(raw, downsample, st, rotate90=False, math_mode=MATH_SHARED):
     pcm = np.zeros(n // max(downsample, 1) + 2, dtype=np.int16)
     m = lib().orc_rtlfm_chain(raw, n, int(downsample), int(bool(rotate90)), st, pcm, math_mode)
     return pcm[:m]
+
+
+def rtlfm_full(raw, downsample, st, post, pcm, rotate90=False, squelch_level=0, post_downsample=1, deemph_a=0,
+               dc_block=False, math_mode=MATH_SHARED):
+    """rtl_fm's full_demod on raw bytes (n, 2); st = int32[5], post = int32[4] carried, pcm = the int16 result buffer
+    (kept between calls like rtl_fm's result[]), all updated in place; returns result_len"""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8).reshape(-1)
+    return lib().orc_rtlfm_full(raw, raw.size // 2, int(downsample), int(bool(rotate90)), int(squelch_level),
+                                int(post_downsample), int(deemph_a), int(bool(dc_block)), st, post, pcm, pcm.size, math_mode)
 
 
 def fm_discriminator(re, im, pre=None, math_mode=MATH_SHARED):

@@ -614,6 +614,50 @@ def test_dsp_unsupported_and_empty():
     device.iir(device.IIR_DC_BLOCK, 0.995, e)
     device.normalize(e, torch.zeros(0, dtype=torch.float64, device="cuda"))
 
+@pytest.mark.parametrize("cfg", [
+    dict(downsample=10, squelch_level=0, post_downsample=1, deemph_a=0, dc_block=False),   # == sdrx_rtlfm_dev
+    dict(downsample=10, squelch_level=0, post_downsample=4, deemph_a=3, dc_block=True),    # wbfm-like post chain
+    dict(downsample=7, squelch_level=0, post_downsample=3, deemph_a=0, dc_block=True, rotate90=True),
+    dict(downsample=10, squelch_level=300, post_downsample=1, deemph_a=5, dc_block=False), # squelch around the level
+    dict(downsample=4, squelch_level=150, post_downsample=2, deemph_a=2, dc_block=True),
+    dict(downsample=1, squelch_level=40, post_downsample=5, deemph_a=7, dc_block=True),
+])
+def test_rtlfm_full_demod_vs_oracle(cfg):
+    """sdrx_rtlfm_full_dev against the literal restatement of rtl_fm's full_demod (parity unpinned: rtl_fm.c needs
+    librtlsdr): 9 channels with amplitudes on both sides of the squelch level (some channels squelched in some calls
+    only, so squelch_hits counts up and resets), four calls of ragged lengths with every state carried: pcm rows
+    (the whole buffer, including what low_pass_simple leaves past its output), the 5 + 4 state words per channel."""
+    rng = np.random.default_rng(hash(tuple(sorted(cfg.items()))) % (1 << 32))
+    nchan, cap = 9, 6000
+    fm = device.RtlFmFull(nchan, **cfg)
+    sts = np.zeros((nchan, 5), dtype=np.int32)
+    posts = np.zeros((nchan, 4), dtype=np.int32)
+    pcm_ref = np.zeros((nchan, cap), dtype=np.int16)
+    pcm = torch.zeros(nchan, cap, dtype=torch.int16, device="cuda")
+    posts[1::2, 0] = 1000000  # a de-emphasis average far outside the int16 range: the kernel's plain-division path
+    posts[2::4, 1] = -777     # a carried dc_avg
+    fm.post_state.copy_(torch.tensor(posts))
+    # rotate_90 works on groups of 4 samples (the reference only ever passes whole radio buffers)
+    lengths = (5004, 4, 4000, 3000) if cfg.get("rotate90") else (5003, 1, 4000, 2999)
+    for call, n in enumerate(lengths):
+        raw = np.zeros((nchan, n, 2), dtype=np.uint8)
+        for c in range(nchan):
+            amp = (2.0, 8.0, 14.0, 20.0, 30.0, 45.0, 60.0, 90.0, 120.0)[(c + 3 * call) % 9]
+            ph = np.cumsum(rng.normal(0.01 * (c + 1), 0.05, n))  # a slowly turning, frequency-modulated carrier
+            raw[c, :, 0] = np.clip(np.round(amp * np.cos(ph) + rng.normal(0, 1, n) + 127), 0, 255)
+            raw[c, :, 1] = np.clip(np.round(amp * np.sin(ph) + rng.normal(0, 1, n) + 127), 0, 255)
+        got_len = fm.demod(torch.tensor(raw, device="cuda"), pcm)
+        for c in range(nchan):
+            want_len = O.rtlfm_full(raw[c], cfg["downsample"], sts[c], posts[c], pcm_ref[c],
+                                    **{k: v for k, v in cfg.items() if k != "downsample"})
+            assert want_len == got_len
+        assert np.array_equal(pcm.cpu().numpy(), pcm_ref), call
+        assert np.array_equal(fm.state[fm.cur].cpu().numpy(), sts), call
+        assert np.array_equal(fm.post_state.cpu().numpy(), posts), call
+    if cfg["squelch_level"]:
+        assert posts[:, 2].max() > 0 and posts[:, 2].min() == 0  # both squelched and open channels were seen
+
+
 # =============================================================================== bit-domain back end
 
 @pytest.mark.parametrize("crc_enable", [True, False])

@@ -476,3 +476,48 @@ def test_dsp_primitive_restatements_properties():
     for mode in (O.MATH_LIBM, O.MATH_SHARED):
         assert np.allclose(O.fft(z, mode), np.fft.fft(z), rtol=0, atol=1e-10)
     assert np.max(np.abs(O.fft(z, O.MATH_SHARED) - O.fft(z, O.MATH_LIBM))) <= 1e-12 * 8 * np.abs(np.fft.fft(z)).max()
+
+
+def test_rtlfm_full_demod_restatement_properties():
+    """rtl_fm's full_demod restatement (parity unpinned: rtl_fm.c needs librtlsdr and the vendored copy does not
+    compile): with every option off it is the plain chain; each stage's defining property on top of that."""
+    rng = np.random.default_rng(3)
+    n = 4000
+    ph = np.cumsum(rng.normal(0.03, 0.05, n))
+    raw = np.zeros((n, 2), dtype=np.uint8)
+    raw[:, 0] = np.clip(np.round(60 * np.cos(ph) + 127), 0, 255)
+    raw[:, 1] = np.clip(np.round(60 * np.sin(ph) + 127), 0, 255)
+
+    def run(**kw):
+        st, post, pcm = np.zeros(5, dtype=np.int32), np.zeros(4, dtype=np.int32), np.zeros(1000, dtype=np.int16)
+        m = O.rtlfm_full(raw, 10, st, post, pcm, **kw)
+        return m, st, post, pcm
+
+    st0 = np.zeros(5, dtype=np.int32)
+    plain = O.rtlfm_chain(raw, 10, st0)
+    m, st, post, pcm = run()
+    assert m == plain.size == 400 and np.array_equal(pcm[:m], plain) and np.array_equal(st, st0) and post[3] == 400
+    # low_pass_simple: sums of 4 (int16 wrap), one duplicate written past the output, result_len = 100
+    m4, _, _, p4 = run(post_downsample=4)
+    assert m4 == 100
+    assert np.array_equal(p4[:100], plain.astype(np.int32).reshape(100, 4).sum(axis=1).astype(np.int16))
+    assert p4[101] == plain[100]  # signal2[i/step + 1] = signal2[i/step]: the untouched sample 100 copied to 101
+    # squelch: the lowpassed rms of this signal is about 10 * 60: closed above that, open below; a closed call gives zeros
+    m, st_s, post_s, p_s = run(squelch_level=1000)
+    assert post_s[2] == 1 and not p_s[:m].any() and st_s[3] == 0 and st_s[4] == 0
+    m, _, post_o, p_o = run(squelch_level=300)
+    assert post_o[2] == 0 and np.array_equal(p_o[:m], plain)
+    # de-emphasis: avg follows the input with the rounded division of rtl_fm.c:607-613
+    m, _, post_d, p_d = run(deemph_a=3)
+    avg = 0
+    for i in range(m):
+        d = int(plain[i]) - avg
+        q = (d + 1) if d > 0 else (d - 1)
+        avg += int(q / 3)  # C division truncates towards zero
+        assert p_d[i] == np.int16(avg)
+    assert post_d[0] == avg
+    # dc block: the block's mean, averaged 1:9 with the carried one (0), is subtracted
+    m, _, post_b, p_b = run(dc_block=True)
+    mean = int(int(plain.astype(np.int64).sum()) / m)
+    a = int((mean + 0) / 10)
+    assert post_b[1] == a and np.array_equal(p_b[:m], (plain.astype(np.int32) - a).astype(np.int16))
