@@ -1,7 +1,8 @@
 /*
  * sdrx.h -- C ABI of libsdrx.so: the MI355X (gfx950) implementation of RadioNode's
  * baseband DSP hot path (FIR Filter + AM / FM / BPSK / QPSK modulators, demodulators), and of
- * the steps on either side of it (raw-byte ingest in front, packet deframing behind).
+ * the steps on either side of it (raw-byte ingest in front; packet deframing and the ones/zeros
+ * confidence walk behind; rtl_fm's full_demod; the DigitalSignalProcessing primitives).
  *
  * Plain pointers and sizes only; no C++ or torch types.  Three layers:
  *   1. device layer  (sdrx_*_dev)  : device pointers + a hipStream_t (void*), asynchronous,
