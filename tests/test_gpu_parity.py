@@ -1095,6 +1095,60 @@ def test_psk_bank_multichannel_device():
                 assert np.array_equal(mine, sts[c].loop_state())
 
 
+def test_config3_full_shape_bank():
+    """BASELINE config 3 at the shape bench.py times (2^14 QPSK channels x 2^12 samples, two blocks): the bank is
+    filled with 64 distinct signals repeated 256 times, so (i) every copy must give the same decisions and state as
+    the first (channels are independent wherever they sit in the grid), and (ii) the 64 distinct channels are checked
+    against the oracle's full chain, decisions and all loop-state doubles, bit for bit."""
+    nchan, n, distinct = 1 << 14, 1 << 12, 64
+    bank = device.PskBank(_lib.QPSK, nchan, n)
+    sts = [O.psk_new(O.QPSK, math_mode=O.MATH_SHARED) for _ in range(distinct)]
+    for blk in range(2):
+        sig = np.stack([psk_test_signal(O.QPSK, n // 8, seed=7000 + 100 * blk + c, phase_deg=(29 * c) % 360, snr_db=16.0,
+                                        timing_offset=c % 8).reshape(n, 2) for c in range(distinct)])
+        iq = torch.tensor(sig, device="cuda").repeat(nchan // distinct, 1, 1).contiguous()
+        out = torch.zeros(nchan, bank.n_dec, dtype=torch.uint8, device="cuda")
+        bank.demod(iq, out)
+        torch.cuda.synchronize()
+        o = out.view(nchan // distinct, distinct, -1)
+        assert torch.equal(o, o[0:1].expand_as(o))
+        stt = bank.states.view(nchan // distinct, distinct, -1)
+        assert torch.equal(stt, stt[0:1].expand_as(stt))
+        got, hs = out[:distinct].cpu().numpy(), bank.states[:distinct].cpu().numpy()
+        for c in range(distinct):
+            want = O.psk_demodulate(sts[c], np.ascontiguousarray(sig[c].reshape(-1)))
+            assert np.array_equal(got[c][: want.size].astype(np.float64), want), (blk, c)
+            assert np.array_equal(hs[c][: 8 * 24].view(np.float64), sts[c].loop_state()), (blk, c)
+
+
+def test_config4_full_shape_bank():
+    """BASELINE config 4 at full shape (1024 channels x 2^18 samples of the config-2 chain in one launch): 16 distinct
+    streams repeated 64 times: every copy equals the first; the 16 distinct rows equal the same streams run one channel
+    at a time (a different grid, the same bits) and the oracle on their first 3000 outputs; carried state included."""
+    err, taps = O.fir_design(O.LPF, 64, 2.4e6, 1.0e5)
+    nchan, n, D, distinct = 1024, 1 << 18, 10, 16
+    g = torch.Generator(device="cuda").manual_seed(99)
+    base = torch.randint(-127, 128, (distinct, n, 2), generator=g, device="cuda").to(torch.float64)
+    iq = base.repeat(nchan // distinct, 1, 1).contiguous()
+    n_out = (n + D - 1) // D
+    out = torch.zeros(nchan, n_out, dtype=torch.float64, device="cuda")
+    bankc = device.FirChain(taps, nchan, D)
+    bankc.fir_fmdisc(iq, out)
+    o = out.view(nchan // distinct, distinct, -1)
+    assert torch.equal(o, o[0:1].expand_as(o))
+    for c in range(distinct):
+        one = torch.zeros(1, n_out, dtype=torch.float64, device="cuda")
+        device.FirChain(taps, 1, D).fir_fmdisc(base[c:c + 1].contiguous(), one)
+        assert torch.equal(one[0], out[c]), c
+        m = 3000
+        seg = base[c, : m * D].cpu().numpy()
+        hi, hq, pre = np.zeros(63), np.zeros(63), np.zeros(2)
+        want = np.zeros(m)
+        L.orc_chain_fir_decim_disc(taps, 64, hi, hq, pre, np.ascontiguousarray(seg[:, 0]), np.ascontiguousarray(seg[:, 1]),
+                                   m * D, D, want, O.MATH_SHARED)
+        assert np.array_equal(out[c, :m].cpu().numpy(), want), c
+
+
 def test_psk_loops_one_wave_and_two_wave_forms_agree(monkeypatch):
     """psk_loops_kernel (both loops interleaved in one wave) and psk_loops_split_kernel (timing and carrier
     loop on two waves through an LDS ring) are picked by channel count; forced either way they give the
