@@ -17,6 +17,15 @@
 namespace sdrx {
 namespace {
 
+// read-once / write-once rows: nontemporal accesses (build with -DSDRX_DSP_PLAIN for ordinary ones)
+#ifndef SDRX_DSP_PLAIN
+#define DSP_LOAD(p) __builtin_nontemporal_load(p)
+#define DSP_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define DSP_LOAD(p) (*(p))
+#define DSP_STORE(v, p) (*(p) = (v))
+#endif
+
 struct IirCoef {
     double c[5];
 };
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(64) void iir_kernel(const double *x, double *y, siz
     auto load = [&](size_t s0) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
-            nxt[i] = (c0 + 4 * i + sub < nchan && s0 + col < n) ? x[row0 + (size_t)(4 * i) * pitch + s0] : 0.0;
+            nxt[i] = (c0 + 4 * i + sub < nchan && s0 + col < n) ? DSP_LOAD(x + row0 + (size_t)(4 * i) * pitch + s0) : 0.0;
     };
     load(0);
     for (size_t s0 = 0; s0 < n; s0 += IC) {
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(64) void iir_kernel(const double *x, double *y, siz
         wave_lds_sync();
 #pragma unroll
         for (int i = 0; i < NI; i++)
-            if (c0 + 4 * i + sub < nchan && s0 + col < n) y[row0 + (size_t)(4 * i) * pitch + s0] = tile[(4 * i + sub) * IPITCH + col];
+            if (c0 + 4 * i + sub < nchan && s0 + col < n) DSP_STORE(tile[(4 * i + sub) * IPITCH + col], y + row0 + (size_t)(4 * i) * pitch + s0);
         wave_lds_sync();
     }
     if (carried && l < CW)
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256) void norm_scale_kernel(double *x, size_t n, si
     size_t i0 = (size_t)blockIdx.x * (256 * NORM_PER_THREAD) + threadIdx.x;
     for (int j = 0; j < NORM_PER_THREAD; j++) {
         size_t i = i0 + (size_t)j * 256;
-        if (i < n) xp[i] = (xp[i] / m) * 2.0 - 1.0;
+        if (i < n) DSP_STORE((DSP_LOAD(xp + i) / m) * 2.0 - 1.0, xp + i);
     }
 }
 
