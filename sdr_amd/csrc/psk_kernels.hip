@@ -341,12 +341,13 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
 // the saturating confidence counters in stream order (confidence_counter.cpp:41-61 is not
 // commutative at the rails), so lane 0 folds a chunk's hits sequentially, only for chunks that
 // have any.
-__global__ void __launch_bounds__(256) psk_ambiguity_kernel(int kind, uint8_t *__restrict__ dec, size_t m,
+template <int NT>
+__global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__restrict__ dec, size_t m,
                                                             size_t out_pitch, sdrx_psk_state *__restrict__ states,
                                                             unsigned long long *__restrict__ hits, size_t max_hits)
 {
     __shared__ uint8_t uwc[4][64];
-    __shared__ signed char ev[256];
+    __shared__ signed char ev[NT];
     __shared__ int s_cc[4];
     __shared__ int s_lut, s_nh;
     const unsigned tid = threadIdx.x;
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(256) psk_ambiguity_kernel(int kind, uint8_t *_
     __syncthreads();
     if (m >= (size_t)U) {
         const size_t npos = m - (size_t)U; // i < num_of_points - UW_SIZE
-        for (size_t base = 0; base < npos; base += 256) {
+        for (size_t base = 0; base < npos; base += NT) {
             const size_t i = base + tid;
             int code = -1;
             if (i < npos) {
@@ -390,7 +391,7 @@ __global__ void __launch_bounds__(256) psk_ambiguity_kernel(int kind, uint8_t *_
             ev[tid] = (signed char)code;
             const int any = __syncthreads_or(code >= 0);
             if (any && tid == 0) {
-                for (int t = 0; t < 256; t++) {
+                for (int t = 0; t < NT; t++) {
                     const int cd = ev[t];
                     if (cd < 0) continue;
                     if (kind == SDRX_BPSK) {
@@ -426,7 +427,7 @@ __global__ void __launch_bounds__(256) psk_ambiguity_kernel(int kind, uint8_t *_
     __syncthreads();
     const int lut = s_lut;
     if (lut < 0) return;
-    for (size_t i = tid; i < m; i += 256) {
+    for (size_t i = tid; i < m; i += NT) {
         const unsigned v = d[i];
         unsigned o;
         if (kind == SDRX_BPSK) o = v ^ 1u;                       // LUT_180 = {1,0}, BPSK.cpp:15
@@ -446,8 +447,13 @@ int launch_psk_ambiguity(int kind, uint8_t *decisions, size_t m, size_t nchan, s
     }
     if (nchan == 0) return SDRX_OK;
     if (nchan > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
-    hipLaunchKernelGGL(psk_ambiguity_kernel, dim3((unsigned)nchan), dim3(256), 0, s, kind, decisions, m, out_pitch,
-                       states, (unsigned long long *)nullptr, (size_t)0);
+    // short blocks (config 3: 256 decisions per channel): one wave per channel, four times as many channels in flight
+    if (m <= 2048)
+        hipLaunchKernelGGL(psk_ambiguity_kernel<64>, dim3((unsigned)nchan), dim3(64), 0, s, kind, decisions, m, out_pitch,
+                           states, (unsigned long long *)nullptr, (size_t)0);
+    else
+        hipLaunchKernelGGL(psk_ambiguity_kernel<256>, dim3((unsigned)nchan), dim3(256), 0, s, kind, decisions, m, out_pitch,
+                           states, (unsigned long long *)nullptr, (size_t)0);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }
@@ -457,8 +463,12 @@ int launch_psk_ambiguity_hits(int kind, uint8_t *decisions, size_t m, size_t nch
 {
     if (!decisions || !states) return SDRX_EINVAL;
     if (nchan == 0) return SDRX_OK;
-    hipLaunchKernelGGL(psk_ambiguity_kernel, dim3((unsigned)nchan), dim3(256), 0, s, kind, decisions, m, out_pitch,
-                       states, hits, max_hits);
+    if (m <= 2048)
+        hipLaunchKernelGGL(psk_ambiguity_kernel<64>, dim3((unsigned)nchan), dim3(64), 0, s, kind, decisions, m, out_pitch,
+                           states, hits, max_hits);
+    else
+        hipLaunchKernelGGL(psk_ambiguity_kernel<256>, dim3((unsigned)nchan), dim3(256), 0, s, kind, decisions, m, out_pitch,
+                           states, hits, max_hits);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }
