@@ -126,38 +126,25 @@ SDRX_HD double sdrx_atan_ratio(double ay, double ax)
     return hi - ((t * (s1 + s2) - lo) - t);
 }
 
-/* atan2(y, x), C99 sign/zero conventions for finite inputs; nan in -> nan out. */
+/* atan2(y, x), C99 sign/zero conventions; nan in -> nan out.  Straight-line: the general path always runs
+ * and the special cases (zeros, infinities, nan) are selected over it afterwards, so a 64-lane wave executes
+ * no divergent branch (the arithmetic of every case is what the branching form did: same bits). */
 SDRX_HD double sdrx_atan2(double y, double x)
 {
     const double PI = 3.1415926535897931160e+00, PI_LO = 1.2246467991473531772e-16;
-    const double PIO2 = 1.5707963267948965580e+00;
-    if (x != x || y != y)
-        return x + y;
-    const int yneg = (y < 0.0) || (y == 0.0 && 1.0 / y < 0.0);
-    const int xneg = (x < 0.0) || (x == 0.0 && 1.0 / x < 0.0);
-    if (y == 0.0) {
-        if (!xneg) return y;          /* +-0 */
-        return yneg ? -PI : PI;
-    }
-    if (x == 0.0)
-        return yneg ? -PIO2 : PIO2;
-    const double ay = yneg ? -y : y;
-    const double ax = xneg ? -x : x;
-    double z;
+    const double PIO2 = 1.5707963267948965580e+00, PIO4 = 7.85398163397448278999e-01;
+    const int yneg = __builtin_signbit(y) != 0, xneg = __builtin_signbit(x) != 0;
+    const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
     const int xinf = ax > 1.79769313486231570815e+308;
     const int yinf = ay > 1.79769313486231570815e+308;
-    if (xinf || yinf) {
-        if (xinf && yinf) z = 7.85398163397448278999e-01;
-        else if (yinf) z = PIO2;
-        else z = 0.0;
-    } else {
-        z = sdrx_atan_ratio(ay, ax);
-    }
-    if (!xneg)
-        return yneg ? -z : z;
-    /* second / third quadrant: pi - z, carrying pi's tail */
-    z = PI - (z - PI_LO);
-    return yneg ? -z : z;
+    double z = sdrx_atan_ratio(ay, ax); /* (0,0), infinities: overridden below */
+    z = (xinf || yinf) ? ((xinf && yinf) ? PIO4 : (yinf ? PIO2 : 0.0)) : z;
+    double r = xneg ? PI - (z - PI_LO) : z; /* second / third quadrant: pi - z, carrying pi's tail */
+    r = yneg ? -r : r;
+    r = (x == 0.0) ? (yneg ? -PIO2 : PIO2) : r;
+    r = (y == 0.0) ? (xneg ? (yneg ? -PI : PI) : y) : r; /* +-0 for x >= +0, +-pi for x <= -0 */
+    r = (x != x || y != y) ? x + y : r;
+    return r;
 }
 
 #endif /* SDRX_MATH_H */
