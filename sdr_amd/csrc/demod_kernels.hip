@@ -356,6 +356,35 @@ int launch_fm_demod(const double *re, const double *w1, const double *w2, uint8_
 __device__ __forceinline__ void rtlfm_sum(const uint8_t *__restrict__ x, long long first, long long last, int rotate90,
                                           int &sr, int &sj)
 {
+    // Without rotate_90 the window's sums are plain byte sums: four bytes (two samples) per load, I and Q
+    // picked apart by a byte dot product, 127 per sample taken off at the end (integer arithmetic: exact in any
+    // order).  Half-filled dwords at either end are read as the 16 bits that belong to the window.
+    if (!rotate90 && ((size_t)x & 1) == 0 && last > first) {
+        const unsigned off = (unsigned)(((size_t)x & 3) >> 1); // the row starts on the second half of a dword
+        const uint8_t *xa = x - 2 * off;
+        long long b0 = 2 * (first + off), b1 = 2 * (last + off); // the window's bytes relative to xa
+        unsigned si = 0, sq = 0;
+        if (b0 & 2) {
+            const unsigned v = (unsigned)*(const unsigned short *)(xa + b0);
+            si += v & 0xffu, sq += v >> 8;
+            b0 += 2;
+        }
+        if ((b1 & 2) && b1 > b0) {
+            const unsigned v = (unsigned)*(const unsigned short *)(xa + b1 - 2);
+            si += v & 0xffu, sq += v >> 8;
+            b1 -= 2;
+        }
+        const unsigned *w = (const unsigned *)xa;
+        for (long long d = b0 >> 2; d < (b1 >> 2); d++) {
+            const unsigned v = w[d];
+            si = __builtin_amdgcn_udot4(v, 0x00010001u, si, false);
+            sq = __builtin_amdgcn_udot4(v, 0x01000100u, sq, false);
+        }
+        const int cnt = (int)(last - first);
+        sr += (int)si - 127 * cnt;
+        sj += (int)sq - 127 * cnt;
+        return;
+    }
     for (long long i = first; i < last; i++) { // sample index within the call
         unsigned a = x[2 * i], b = x[2 * i + 1];
         if (rotate90) {
