@@ -355,6 +355,24 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
     sdrx_psk_state *st = states + c;
     uint8_t *d = dec + c * out_pitch;
     const int U = st->uw_size > 64 ? 64 : (st->uw_size < 0 ? 0 : st->uw_size);
+    // short blocks (the one-wave form): the channel's decisions are staged in LDS once, the 16..64 compares of
+    // every position then read LDS instead of issuing a global byte load each
+    constexpr bool STAGED = NT == 64;
+    __shared__ __align__(16) uint8_t sd[STAGED ? 2048 + 16 : 16];
+    const uint8_t *src = d;
+    if constexpr (STAGED) {
+        if ((((size_t)d) & 3) == 0) {
+            for (size_t w = tid; w < (m + 3) / 4; w += NT) {
+                unsigned v = 0;
+                if (4 * w + 4 <= m) v = *(const unsigned *)(d + 4 * w);
+                else for (size_t k = 4 * w; k < m; k++) v |= (unsigned)d[k] << (8 * (k - 4 * w));
+                *(unsigned *)(sd + 4 * w) = v;
+            }
+        } else {
+            for (size_t k = tid; k < m; k += NT) sd[k] = d[k];
+        }
+        src = sd;
+    }
     if (tid < 64 && (int)tid < U) {
         const int idx = (kind == SDRX_BPSK) ? (U - 1 - (int)tid) : (63 - (int)tid); // BPSK.cpp:456, QPSK.cpp:428
         for (int k = 0; k < 4; k++) uwc[k][tid] = (uint8_t)st->uw[k][idx];
@@ -371,7 +389,7 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
                 if (kind == SDRX_BPSK) {
                     bool m0 = true, m180 = true;
                     for (int j = 0; j < U && (m0 || m180); j++) {
-                        uint8_t v = d[i + j];
+                        uint8_t v = src[i + j];
                         m0 = m0 && (v == uwc[0][j]);
                         m180 = m180 && (v == uwc[1][j]);
                     }
@@ -379,7 +397,7 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
                 } else {
                     int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
                     for (int j = 0; j < U; j++) {
-                        uint8_t v = d[i + j];
+                        uint8_t v = src[i + j];
                         if (v == uwc[0][j]) cnt0++;
                         else if (v == uwc[1][j]) cnt1++;
                         else if (v == uwc[2][j]) cnt2++;
