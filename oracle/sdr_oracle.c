@@ -5,6 +5,13 @@
  * All arithmetic is IEEE fp64, one rounding per operation, in the reference's
  * source order (the reference's unit-test build is -O0, RadioNode/CMakeLists.txt:8-10),
  * so compile with -ffp-contract=off.
+ *
+ * Pinned by (a) every golden vector of the reference's own unit tests (tests/golden/reference_vectors.npz,
+ * tests/test_oracle_golden.py), (b) the reference's classes compiled from /root/reference (oracle/_ref,
+ * tests/test_oracle_vs_ref.py, build container only) and (c) vectors those compiled classes produced
+ * (tests/golden/ref_fixtures.npz, tests/test_ref_fixtures.py, anywhere).  Parity unpinned (no reference vector and
+ * not buildable here): the u8 conversions and rtl_fm's full_demod (orc_u8_*, orc_rtlfm_*), checked by their
+ * defining properties only.
  */
 #include "sdr_oracle.h"
 
