@@ -65,6 +65,12 @@ int sdrx_init(int device);           /* hipSetDevice + constants; idempotent per
 int sdrx_device_count(void);
 const char *sdrx_last_error(void);   /* thread-local message of the last failure */
 const char *sdrx_version(void);
+/* Experiment switches (DESIGN.md "Experiment switches"): the SDRX_* environment variables are read once, when the
+ * library is first used; sdrx_tune(name, value) sets one afterwards (value NULL or "" = its default).  None of them
+ * changes results.  Not to be called while launches are in flight on other threads. */
+int sdrx_tune(const char *name, const char *value);
+/* The kernel (with its template arguments) the last launch on this thread picked: bench.py's roofline.kernel. */
+const char *sdrx_last_kernel(void);
 
 /* ------------------------------------------------------------------ 1. device layer */
 

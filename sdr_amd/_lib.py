@@ -60,6 +60,8 @@ SIGNATURES = {
     "sdrx_device_count": (C.c_int, []),
     "sdrx_last_error": (C.c_char_p, []),
     "sdrx_version": (C.c_char_p, []),
+    "sdrx_tune": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "sdrx_last_kernel": (C.c_char_p, []),
     "sdrx_fir_dev": (C.c_int, [C.POINTER(FirJob)]),
     "sdrx_fir_am_dev": (C.c_int, [C.POINTER(FirJob)]),
     "sdrx_fir_fmdisc_dev": (C.c_int, [C.POINTER(FirJob)]),

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -56,24 +57,32 @@ struct Scratch {
     }
 };
 
-static std::mutex g_mu;
-static double *g_mf_taps = nullptr;
-static int g_mf_taps_dev = -1;
+thread_local LastKernel t_last_kernel;
 
-const double *psk_mf_taps_dev()
+static int env_int(const char *name, int dflt)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    if (g_mf_taps && g_mf_taps_dev == dev) return g_mf_taps;
-    double rev[129];
-    for (int k = 0; k < 129; k++) rev[k] = RRC_COEFF[129 - k - 1]; // h[k] multiplies x[i-k]: BPSK.cpp:283
-    double *p = nullptr;
-    if (hipMalloc((void **)&p, sizeof(rev)) != hipSuccess) return nullptr;
-    if (hipMemcpy(p, rev, sizeof(rev), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    g_mf_taps = p;
-    g_mf_taps_dev = dev;
-    return p;
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+static int kernel_family(const char *v) { return !v ? 0 : (strcmp(v, "tile") == 0 ? 1 : (strcmp(v, "systolic") == 0 ? 2 : 0)); }
+
+Tuning &tuning()
+{
+    static Tuning t = [] { // the environment is read here, once; never in a launch path
+        Tuning d, x;
+        x.fir_r = env_int("SDRX_FIR_R", d.fir_r);
+        x.fir_kernel = kernel_family(getenv("SDRX_FIR_KERNEL"));
+        x.fir_waves = env_int("SDRX_FIR_WAVES", d.fir_waves);
+        x.fir_lds_pad_kb = env_int("SDRX_FIR_LDS_PAD_KB", d.fir_lds_pad_kb);
+        x.fir_nt = env_int("SDRX_FIR_NT", d.fir_nt);
+        x.fir_lds_soft_kb = env_int("SDRX_FIR_LDS_SOFT_KB", d.fir_lds_soft_kb);
+        x.psk_split = env_int("SDRX_PSK_SPLIT", d.psk_split);
+        x.psk_overlap = env_int("SDRX_PSK_OVERLAP", d.psk_overlap);
+        x.iir_cw = env_int("SDRX_IIR_CW", d.iir_cw);
+        return x;
+    }();
+    return t;
 }
 
 // Pinned host staging + device mirror, grown on demand, owned by one host-layer object.
@@ -136,6 +145,7 @@ extern "C" int sdrx_init(int device)
     SDRX_HIP(hipSetDevice(device));
     SDRX_HIP(hipFree(nullptr));
     (void)am_threshold_sq();
+    (void)tuning();
     return SDRX_OK;
 }
 
@@ -147,6 +157,46 @@ extern "C" int sdrx_device_count(void)
 }
 
 extern "C" const char *sdrx_last_error(void) { return g_err; }
+
+extern "C" int sdrx_tune(const char *name, const char *value)
+{
+    if (!name) return SDRX_EINVAL;
+    Tuning &t = tuning();
+    const Tuning d;
+    const bool dflt = !value || !*value;
+    const int v = dflt ? 0 : atoi(value);
+    if (strcmp(name, "SDRX_FIR_R") == 0) t.fir_r = dflt ? d.fir_r : v;
+    else if (strcmp(name, "SDRX_FIR_KERNEL") == 0) t.fir_kernel = dflt ? 0 : kernel_family(value);
+    else if (strcmp(name, "SDRX_FIR_WAVES") == 0) t.fir_waves = dflt ? d.fir_waves : v;
+    else if (strcmp(name, "SDRX_FIR_LDS_PAD_KB") == 0) t.fir_lds_pad_kb = dflt ? d.fir_lds_pad_kb : v;
+    else if (strcmp(name, "SDRX_FIR_NT") == 0) t.fir_nt = dflt ? d.fir_nt : v;
+    else if (strcmp(name, "SDRX_FIR_LDS_SOFT_KB") == 0) t.fir_lds_soft_kb = dflt ? d.fir_lds_soft_kb : v;
+    else if (strcmp(name, "SDRX_PSK_SPLIT") == 0) t.psk_split = dflt ? d.psk_split : v;
+    else if (strcmp(name, "SDRX_PSK_OVERLAP") == 0) t.psk_overlap = dflt ? d.psk_overlap : v;
+    else if (strcmp(name, "SDRX_IIR_CW") == 0) t.iir_cw = dflt ? d.iir_cw : v;
+    else {
+        set_error("sdrx_tune: unknown switch %s", name);
+        return SDRX_EINVAL;
+    }
+    return SDRX_OK;
+}
+
+extern "C" const char *sdrx_last_kernel(void)
+{
+    static thread_local char buf[160];
+    const LastKernel &k = t_last_kernel;
+    static const char *const lay[] = {"REAL", "IQ_SPLIT", "IQ_INTERLEAVED", "IQ_U8"};
+    static const char *const epi[] = {"EPI_STORE", "EPI_AM", "EPI_DISC"};
+    if (strcmp(k.family, "fir_systolic_kernel") == 0)
+        snprintf(buf, sizeof(buf), "fir_systolic_kernel<D=%d, %s, %s%s>", k.a, lay[k.b & 3], epi[k.c % 3], k.d ? ", fma" : "");
+    else if (strcmp(k.family, "fir_tile_kernel") == 0)
+        snprintf(buf, sizeof(buf), "fir_tile_kernel<R=%d, %s, %s%s>", k.a, lay[k.b & 3], epi[k.c % 3], k.d ? ", fma" : "");
+    else if (strncmp(k.family, "psk_loops", 9) == 0)
+        snprintf(buf, sizeof(buf), "%s<%s>", k.family, k.a == SDRX_BPSK ? "BPSK" : "QPSK");
+    else
+        snprintf(buf, sizeof(buf), "%s", k.family);
+    return buf;
+}
 extern "C" const char *sdrx_version(void) { return "sdrx 0.1 (gfx950)"; }
 
 // =========================================================================== 1. device layer
@@ -244,7 +294,8 @@ extern "C" size_t sdrx_psk_work_bytes(size_t n, size_t nchan)
 }
 
 static int mf_launch(const double *iq, size_t n, size_t nchan, size_t in_pitch, double *mf_iq, size_t mf_pitch,
-                     double *zero_state, double *dummy_state, hipStream_t stream)
+                     double *zero_state, double *dummy_state, hipStream_t stream, int *offs_buf = nullptr,
+                     unsigned offs_cap = 0)
 {
     const double *taps = psk_mf_taps_dev();
     if (!taps) {
@@ -272,7 +323,7 @@ static int mf_launch(const double *iq, size_t n, size_t nchan, size_t in_pitch, 
     j.out_pitch = mf_pitch;
     j.n_out = n / 4; // memcpy of number_of_points/4 values: BPSK.cpp:292-293
     j.stream = stream;
-    return launch_fir(&j, EPI_STORE);
+    return launch_fir(&j, EPI_STORE, offs_buf, offs_cap);
 }
 
 extern "C" int sdrx_psk_demod_dev(int kind, const double *iq, size_t n, size_t nchan, size_t in_pitch,
@@ -295,22 +346,25 @@ extern "C" int sdrx_psk_demod_dev(int kind, const double *iq, size_t n, size_t n
     return launch_psk_ambiguity(kind, out, (m + 1) / 2, nchan, out_pitch, states, s);
 }
 
-static Scratch g_mf_scratch;
+// sdrx_psk_matched_filter_dev's zero / dummy state rows: one buffer per device, grown on demand.  The lock is held
+// from the size check to the launch, and growing waits for the device before it frees, so a buffer is never freed
+// under a launch in flight (host threads of different radios may call concurrently: rtlsdr_receiver.cpp:191-194).
+static std::mutex g_mf_scratch_mu;
+static std::map<int, Scratch> g_mf_scratch;
 
 extern "C" int sdrx_psk_matched_filter_dev(const double *iq, size_t n, size_t nchan, size_t in_pitch, double *mf_iq,
                                            size_t mf_pitch, void *stream)
 {
     if (!iq || !mf_iq) return SDRX_EINVAL;
-    // (psk_mf_taps_dev takes g_mu itself: this entry point used to hold it across the call and deadlocked)
-    static std::mutex scratch_mu;
+    int dev = 0;
+    SDRX_HIP(hipGetDevice(&dev));
     const size_t st_bytes = align256(nchan * MF_STATE * sizeof(double));
-    {
-        std::lock_guard<std::mutex> lk(scratch_mu);
-        int rc = g_mf_scratch.ensure(2 * st_bytes);
-        if (rc) return rc;
-    }
-    return mf_launch(iq, n, nchan, in_pitch, mf_iq, mf_pitch, (double *)g_mf_scratch.p,
-                     (double *)((unsigned char *)g_mf_scratch.p + st_bytes), (hipStream_t)stream);
+    std::lock_guard<std::mutex> lk(g_mf_scratch_mu);
+    Scratch &sc = g_mf_scratch[dev];
+    int rc = sc.ensure(2 * st_bytes);
+    if (rc) return rc;
+    return mf_launch(iq, n, nchan, in_pitch, mf_iq, mf_pitch, (double *)sc.p, (double *)((unsigned char *)sc.p + st_bytes),
+                     (hipStream_t)stream);
 }
 
 extern "C" int sdrx_psk_loops_dev(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch,

@@ -406,10 +406,7 @@ extern "C" int sdrx_iir_dev(int kind, const double *coef, const double *x, doubl
     for (int j = 0; j < ncoef[kind]; j++) k.c[j] = coef[j];
     // rows per wave: the largest of 64 / 16 / 4 that still gives every SIMD of the part (1024) a wave
     int cw = nchan >= 64 * 1024 ? 64 : (nchan >= 16 * 1024 ? 16 : 4);
-    if (const char *e = getenv("SDRX_IIR_CW")) {
-        int v = atoi(e);
-        if (v == 64 || v == 16 || v == 4) cw = v;
-    }
+    if (const int v = tuning().iir_cw; v == 64 || v == 16 || v == 4) cw = v;
     hipStream_t s = (hipStream_t)stream;
     switch (kind) {
     case K_DC: launch_iir<K_DC>(cw, x, y, n, nchan, pitch, k, state, s); break;

@@ -42,16 +42,16 @@ namespace sdrx {
 #undef FT
 #undef SDRX_FNS
 
-namespace f32 { int launch_fir_impl(const sdrx_fir_job *job, FirEpilogue epi); } // fir_kernels_f32.hip
+namespace f32 { int launch_fir_impl(const sdrx_fir_job *job, FirEpilogue epi, int *offs_buf, unsigned offs_cap); } // fir_kernels_f32.hip
 
-int launch_fir(const sdrx_fir_job *job, FirEpilogue epi)
+int launch_fir(const sdrx_fir_job *job, FirEpilogue epi, int *offs_buf, unsigned offs_cap)
 {
-    if (job && job->dtype == SDRX_F32) return f32::launch_fir_impl(job, epi);
+    if (job && job->dtype == SDRX_F32) return f32::launch_fir_impl(job, epi, offs_buf, offs_cap);
     if (job && job->dtype != SDRX_F64) {
         set_error("sdrx_fir*_dev: unknown dtype %d", job->dtype);
         return SDRX_EINVAL;
     }
-    return f64::launch_fir_impl(job, epi);
+    return f64::launch_fir_impl(job, epi, offs_buf, offs_cap);
 }
 
 } // namespace sdrx

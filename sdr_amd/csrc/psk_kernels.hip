@@ -14,45 +14,51 @@
 #include "sdrx_internal.h"
 
 #include <cstdlib>
+#include <mutex>
 
 #include "../../include/sdrx_math.h"
 
 namespace sdrx {
 
-const double RRC_COEFF[129] = { // MATLAB rcosine(1/8,1,'sqrt',0.5,8): values of BPSK.cpp:18-50 / QPSK.cpp:32-64
-    -0.000882663055055987, -0.000746201590523265, -0.000336789968798916, 0.000225038893553655,
-    0.000757880681389978,  0.001077943504359050,  0.001062303725777150,  0.000695521249813576,
-    8.24465490986367e-05,  -0.000579554041955506, -0.001062303725777150, -0.001183702054816000,
-    -0.000874477709296126, -0.000211083163638599, 0.000599193283619645,  0.001279536876191750,
-    0.001573979573701230,  0.001338143762729140,  0.000599193283619642,  -0.000438236415412023,
-    -0.001446863119017230, -0.002078893324143190, -0.002084671221261930, -0.001408617284422990,
-    -0.000227352605090172, 0.001088699270085450,  0.002084671221261940,  0.002371289907799650,
-    0.001768388256576610,  0.000391988582678128,  -0.001351122110122730, -0.002869993360503870,
-    -0.003572683794274230, -0.003072685906611650, -0.001351122110122720, 0.001186107048403510,
-    0.003789403406949890,  0.005575980755162950,  0.005816670050933640,  0.004213278581633850,
-    0.001071805138282270,  -0.002702696087965530, -0.005816670050933650, -0.006968745846090550,
-    -0.005305164769729840, -0.000815536975401244, 0.005468827588591990,  0.011573823048484000,
-    0.015005271935951800,  0.013430574641186900,  0.005468827588591980,  -0.008615615450369140,
-    -0.026525823848649200, -0.044008760276746200, -0.055452254485567400, -0.054931750238658300,
-    -0.037513179839879400, -0.000532386899804849, 0.055452254485567400,  0.126288206185736000,
-    0.204577471545948000,  0.280728910881642000,  0.344536138081295000,  0.386975375596443000,
-    0.401855774335913000,  0.386975375596443000,  0.344536138081295000,  0.280728910881642000,
-    0.204577471545948000,  0.126288206185736000,  0.055452254485567400,  -0.000532386899804849,
-    -0.037513179839879400, -0.054931750238658300, -0.055452254485567400, -0.044008760276746200,
-    -0.026525823848649200, -0.008615615450369140, 0.005468827588591980,  0.013430574641186900,
-    0.015005271935951800,  0.011573823048484000,  0.005468827588591990,  -0.000815536975401244,
-    -0.005305164769729840, -0.006968745846090550, -0.005816670050933650, -0.002702696087965530,
-    0.001071805138282270,  0.004213278581633850,  0.005816670050933640,  0.005575980755162950,
-    0.003789403406949890,  0.001186107048403510,  -0.001351122110122720, -0.003072685906611650,
-    -0.003572683794274230, -0.002869993360503870, -0.001351122110122730, 0.000391988582678128,
-    0.001768388256576610,  0.002371289907799650,  0.002084671221261940,  0.001088699270085450,
-    -0.000227352605090172, -0.001408617284422990, -0.002084671221261930, -0.002078893324143190,
-    -0.001446863119017230, -0.000438236415412023, 0.000599193283619642,  0.001338143762729140,
-    0.001573979573701230,  0.001279536876191750,  0.000599193283619645,  -0.000211083163638599,
-    -0.000874477709296126, -0.001183702054816000, -0.001062303725777150, -0.000579554041955506,
-    8.24465490986367e-05,  0.000695521249813576,  0.001062303725777150,  0.001077943504359050,
-    0.000757880681389978,  0.000225038893553655,  -0.000336789968798916, -0.000746201590523265,
-    -0.000882663055055987};
+// MATLAB rcosine(1/8,1,'sqrt',0.5,8): values of BPSK.cpp:18-50 / QPSK.cpp:32-64.  ONE literal list: the host table
+// (BPSK::RRC_COEFF through sdrx_rrc_coeff()) and the device table below are both made from it.
+#define SDRX_RRC_VALUES \
+    -0.000882663055055987, -0.000746201590523265, -0.000336789968798916, 0.000225038893553655, \
+    0.000757880681389978,  0.001077943504359050,  0.001062303725777150,  0.000695521249813576, \
+    8.24465490986367e-05,  -0.000579554041955506, -0.001062303725777150, -0.001183702054816000, \
+    -0.000874477709296126, -0.000211083163638599, 0.000599193283619645,  0.001279536876191750, \
+    0.001573979573701230,  0.001338143762729140,  0.000599193283619642,  -0.000438236415412023, \
+    -0.001446863119017230, -0.002078893324143190, -0.002084671221261930, -0.001408617284422990, \
+    -0.000227352605090172, 0.001088699270085450,  0.002084671221261940,  0.002371289907799650, \
+    0.001768388256576610,  0.000391988582678128,  -0.001351122110122730, -0.002869993360503870, \
+    -0.003572683794274230, -0.003072685906611650, -0.001351122110122720, 0.001186107048403510, \
+    0.003789403406949890,  0.005575980755162950,  0.005816670050933640,  0.004213278581633850, \
+    0.001071805138282270,  -0.002702696087965530, -0.005816670050933650, -0.006968745846090550, \
+    -0.005305164769729840, -0.000815536975401244, 0.005468827588591990,  0.011573823048484000, \
+    0.015005271935951800,  0.013430574641186900,  0.005468827588591980,  -0.008615615450369140, \
+    -0.026525823848649200, -0.044008760276746200, -0.055452254485567400, -0.054931750238658300, \
+    -0.037513179839879400, -0.000532386899804849, 0.055452254485567400,  0.126288206185736000, \
+    0.204577471545948000,  0.280728910881642000,  0.344536138081295000,  0.386975375596443000, \
+    0.401855774335913000,  0.386975375596443000,  0.344536138081295000,  0.280728910881642000, \
+    0.204577471545948000,  0.126288206185736000,  0.055452254485567400,  -0.000532386899804849, \
+    -0.037513179839879400, -0.054931750238658300, -0.055452254485567400, -0.044008760276746200, \
+    -0.026525823848649200, -0.008615615450369140, 0.005468827588591980,  0.013430574641186900, \
+    0.015005271935951800,  0.011573823048484000,  0.005468827588591990,  -0.000815536975401244, \
+    -0.005305164769729840, -0.006968745846090550, -0.005816670050933650, -0.002702696087965530, \
+    0.001071805138282270,  0.004213278581633850,  0.005816670050933640,  0.005575980755162950, \
+    0.003789403406949890,  0.001186107048403510,  -0.001351122110122720, -0.003072685906611650, \
+    -0.003572683794274230, -0.002869993360503870, -0.001351122110122730, 0.000391988582678128, \
+    0.001768388256576610,  0.002371289907799650,  0.002084671221261940,  0.001088699270085450, \
+    -0.000227352605090172, -0.001408617284422990, -0.002084671221261930, -0.002078893324143190, \
+    -0.001446863119017230, -0.000438236415412023, 0.000599193283619642,  0.001338143762729140, \
+    0.001573979573701230,  0.001279536876191750,  0.000599193283619645,  -0.000211083163638599, \
+    -0.000874477709296126, -0.001183702054816000, -0.001062303725777150, -0.000579554041955506, \
+    8.24465490986367e-05,  0.000695521249813576,  0.001062303725777150,  0.001077943504359050, \
+    0.000757880681389978,  0.000225038893553655,  -0.000336789968798916, -0.000746201590523265, \
+    -0.000882663055055987
+
+const double RRC_COEFF[129] = {SDRX_RRC_VALUES};
+
 
 #define SDRX_SGN(v) (((v) == 0.0) ? 0.0 : (((v) < 0.0) ? -1.0 : 1.0)) /* BPSK.h:16 */
 
@@ -308,8 +314,7 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
     size_t blocks = (nchan + 63) / 64;
     if (blocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
     // few channels (fewer waves than SIMDs): give each 64-channel group a second SIMD
-    const char *se = getenv("SDRX_PSK_SPLIT"); // "0" / "1" force one form (tests, experiments)
-    const int split_env = se ? atoi(se) : -1;
+    const int split_env = tuning().psk_split; // 0 / 1 force one form (tests, experiments)
     const bool split = split_env >= 0 ? split_env != 0 : blocks <= 2048;
     if (run_timing && run_phase && split) {
         if (kind == SDRX_BPSK)
@@ -319,6 +324,7 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
             hipLaunchKernelGGL(psk_loops_split_kernel<SDRX_QPSK>, dim3((unsigned)blocks), dim3(128), 0, s,
                                (const double2 *)mf_iq, m, nchan, mf_pitch, states, decisions, out_pitch);
         SDRX_HIP(hipGetLastError());
+        t_last_kernel = {"psk_loops_split_kernel", kind, 0, 0, 0};
         return SDRX_OK;
     }
     typedef void (*fn_t)(double2 *, size_t, size_t, size_t, sdrx_psk_state *, uint8_t *, size_t);
@@ -332,6 +338,7 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64), 0, s, (double2 *)mf_iq, m, nchan, mf_pitch, states, decisions,
                        out_pitch);
     SDRX_HIP(hipGetLastError());
+    t_last_kernel = {"psk_loops_kernel", kind, run_timing, run_phase, 0};
     return SDRX_OK;
 }
 
@@ -495,40 +502,36 @@ int launch_psk_ambiguity_hits(int kind, uint8_t *decisions, size_t m, size_t nch
 //
 // out[i] (+)= sum_j up[i-j] * RRC[128-j], j ascending, up = symbols zero-stuffed by 8: only
 // j == i (mod 8) meets a symbol, every other product is an exact zero and is skipped.
-__device__ const double d_rrc[129] = {
-    -0.000882663055055987, -0.000746201590523265, -0.000336789968798916, 0.000225038893553655,
-    0.000757880681389978,  0.001077943504359050,  0.001062303725777150,  0.000695521249813576,
-    8.24465490986367e-05,  -0.000579554041955506, -0.001062303725777150, -0.001183702054816000,
-    -0.000874477709296126, -0.000211083163638599, 0.000599193283619645,  0.001279536876191750,
-    0.001573979573701230,  0.001338143762729140,  0.000599193283619642,  -0.000438236415412023,
-    -0.001446863119017230, -0.002078893324143190, -0.002084671221261930, -0.001408617284422990,
-    -0.000227352605090172, 0.001088699270085450,  0.002084671221261940,  0.002371289907799650,
-    0.001768388256576610,  0.000391988582678128,  -0.001351122110122730, -0.002869993360503870,
-    -0.003572683794274230, -0.003072685906611650, -0.001351122110122720, 0.001186107048403510,
-    0.003789403406949890,  0.005575980755162950,  0.005816670050933640,  0.004213278581633850,
-    0.001071805138282270,  -0.002702696087965530, -0.005816670050933650, -0.006968745846090550,
-    -0.005305164769729840, -0.000815536975401244, 0.005468827588591990,  0.011573823048484000,
-    0.015005271935951800,  0.013430574641186900,  0.005468827588591980,  -0.008615615450369140,
-    -0.026525823848649200, -0.044008760276746200, -0.055452254485567400, -0.054931750238658300,
-    -0.037513179839879400, -0.000532386899804849, 0.055452254485567400,  0.126288206185736000,
-    0.204577471545948000,  0.280728910881642000,  0.344536138081295000,  0.386975375596443000,
-    0.401855774335913000,  0.386975375596443000,  0.344536138081295000,  0.280728910881642000,
-    0.204577471545948000,  0.126288206185736000,  0.055452254485567400,  -0.000532386899804849,
-    -0.037513179839879400, -0.054931750238658300, -0.055452254485567400, -0.044008760276746200,
-    -0.026525823848649200, -0.008615615450369140, 0.005468827588591980,  0.013430574641186900,
-    0.015005271935951800,  0.011573823048484000,  0.005468827588591990,  -0.000815536975401244,
-    -0.005305164769729840, -0.006968745846090550, -0.005816670050933650, -0.002702696087965530,
-    0.001071805138282270,  0.004213278581633850,  0.005816670050933640,  0.005575980755162950,
-    0.003789403406949890,  0.001186107048403510,  -0.001351122110122720, -0.003072685906611650,
-    -0.003572683794274230, -0.002869993360503870, -0.001351122110122730, 0.000391988582678128,
-    0.001768388256576610,  0.002371289907799650,  0.002084671221261940,  0.001088699270085450,
-    -0.000227352605090172, -0.001408617284422990, -0.002084671221261930, -0.002078893324143190,
-    -0.001446863119017230, -0.000438236415412023, 0.000599193283619642,  0.001338143762729140,
-    0.001573979573701230,  0.001279536876191750,  0.000599193283619645,  -0.000211083163638599,
-    -0.000874477709296126, -0.001183702054816000, -0.001062303725777150, -0.000579554041955506,
-    8.24465490986367e-05,  0.000695521249813576,  0.001062303725777150,  0.001077943504359050,
-    0.000757880681389978,  0.000225038893553655,  -0.000336789968798916, -0.000746201590523265,
-    -0.000882663055055987};
+// (not const: a const namespace-scope variable has internal linkage and is folded away, and then the runtime has
+// no symbol for hipGetSymbolAddress to find)
+__device__ double d_rrc[129] = {SDRX_RRC_VALUES};
+
+// The matched filter multiplies x[i-k] by RRC[128-k] (BPSK.cpp:283) and the table is symmetric bit for bit (checked
+// here at compile time), so the FIR kernel's tap array h[k] IS d_rrc: no reversed copy, nothing to allocate.
+constexpr double rrc_ct[129] = {SDRX_RRC_VALUES};
+constexpr bool rrc_symmetric()
+{
+    for (int k = 0; k < 129; k++)
+        if (rrc_ct[k] != rrc_ct[128 - k]) return false;
+    return true;
+}
+static_assert(rrc_symmetric(), "RRC_COEFF must equal its own reverse for d_rrc to serve as the matched filter's taps");
+
+const double *psk_mf_taps_dev()
+{
+    static std::mutex mu;
+    static const double *ptr[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!ptr[dev]) { // each GPU holds its own copy of the table at its own address
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(d_rrc)) != hipSuccess) return nullptr;
+        ptr[dev] = (const double *)p;
+    }
+    return ptr[dev];
+}
+
 
 __global__ void __launch_bounds__(256) psk_modulate_kernel(int kind, const uint8_t *__restrict__ sym, size_t len,
                                                            double *__restrict__ out_re,

@@ -30,9 +30,33 @@ double am_threshold_sq();
 // 32-bit magic for q = u / d, exact for u < 2^20, 1 <= d < 2^11  (q = (u * magic) >> 32)
 inline unsigned magic_u32(unsigned d) { return (unsigned)((0x100000000ULL + d - 1) / d); }
 
+// Experiment switches.  Read from the environment ONCE, when the library is first used;
+// sdrx_tune() changes one afterwards (tests, experiments).  No launch path calls getenv.
+struct Tuning {
+    int fir_r = 0;            // SDRX_FIR_R: outputs per lane of the workgroup-tile kernel (0 = the launcher's choice)
+    int fir_kernel = 0;       // SDRX_FIR_KERNEL: 0 auto, 1 "tile", 2 "systolic"
+    int fir_waves = 1;        // SDRX_FIR_WAVES: waves per workgroup of the systolic kernel
+    int fir_lds_pad_kb = 0;   // SDRX_FIR_LDS_PAD_KB: extra LDS per systolic workgroup (lowers the occupancy)
+    int fir_nt = 256;         // SDRX_FIR_NT: lanes per workgroup tile
+    int fir_lds_soft_kb = 64; // SDRX_FIR_LDS_SOFT_KB: preferred LDS per workgroup tile
+    int psk_split = -1;       // SDRX_PSK_SPLIT: -1 auto, 0 one-wave loops, 1 two-wave loops
+    int psk_overlap = -1;     // SDRX_PSK_OVERLAP: -1 auto, 0 one stream, 1 block pipeline on two streams
+    int iir_cw = 0;           // SDRX_IIR_CW: rows per wave of the recurrences (0 = by bank size)
+};
+Tuning &tuning();
+
+// What the launchers picked last on this thread (sdrx_last_kernel(): bench.py's roofline.kernel).
+struct LastKernel {
+    const char *family = "";  // "fir_systolic_kernel", "fir_tile_kernel", "fir_mfma_kernel", "psk_loops_split_kernel", ...
+    int a = 0, b = 0, c = 0, d = 0; // family-specific template arguments
+};
+extern thread_local LastKernel t_last_kernel;
+
 // launchers implemented in fir_kernels.hip
 enum FirEpilogue { EPI_STORE = 0, EPI_AM = 1, EPI_DISC = 2 };
-int launch_fir(const sdrx_fir_job *job, FirEpilogue epi);
+// offs_buf (optional): device memory for the workgroup-tile kernel's window-offset table (offs_cap ints), filled by a
+// kernel on the job's stream -- the launch then allocates nothing even for a geometry not seen before.
+int launch_fir(const sdrx_fir_job *job, FirEpilogue epi, int *offs_buf = nullptr, unsigned offs_cap = 0);
 int launch_fir_mfma(const sdrx_fir_job *job, size_t n_out); // fir_mfma.hip: fast mode 2, fp64 only
 
 // demod_kernels.hip

@@ -489,11 +489,11 @@ def test_ones_zeros_confidence_walk(n):
 
 @pytest.mark.parametrize("cw", [4, 16, 64])
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 15, 16, 17, 18, 33, 1000, 4099])
-def test_dsp_recurrences_bit_exact(n, cw, monkeypatch):
+def test_dsp_recurrences_bit_exact(n, cw, tune):
     """(cw = rows per wave: the launcher's three kernel shapes.)  DC_Filter, LowPassFilter, NotchFilter, FirstOrderDigitalIntegration: 70 channels (more than one wave, ragged
     last wave), three calls in a row so that the carried state (lowpass, notch) and the restart (dc block,
     integrate) are both seen; every row equals the oracle's bit for bit."""
-    monkeypatch.setenv("SDRX_IIR_CW", str(cw))
+    tune("SDRX_IIR_CW", cw)
     rng = np.random.default_rng(1000 + n)
     nchan = 70
     epow = device.lowpass1_coef(3000.0, 1.0 / 48000.0)
@@ -1149,7 +1149,7 @@ def test_config4_full_shape_bank():
         assert np.array_equal(out[c, :m].cpu().numpy(), want), c
 
 
-def test_psk_loops_one_wave_and_two_wave_forms_agree(monkeypatch):
+def test_psk_loops_one_wave_and_two_wave_forms_agree(tune):
     """psk_loops_kernel (both loops interleaved in one wave) and psk_loops_split_kernel (timing and carrier
     loop on two waves through an LDS ring) are picked by channel count; forced either way they give the
     same decisions and state, and both match the oracle (odd lengths, 3 blocks, 70 channels)."""
@@ -1161,7 +1161,7 @@ def test_psk_loops_one_wave_and_two_wave_forms_agree(monkeypatch):
             x = torch.tensor(np.stack([np.asarray(z).reshape(-1, 2) for z in iqs]), device="cuda")
             res = {}
             for force in ("0", "1"):
-                monkeypatch.setenv("SDRX_PSK_SPLIT", force)
+                tune("SDRX_PSK_SPLIT", force)
                 b = device.PskBank(lk, nchan, n)
                 outs = []
                 for _ in range(3):
