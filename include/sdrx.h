@@ -234,6 +234,20 @@ void sdrx_psk_state_init_qpsk(sdrx_psk_state *s, const double *uw64, size_t uw_l
 size_t sdrx_psk_work_bytes(size_t n, size_t nchan);
 int sdrx_psk_demod_dev(int kind, const double *iq, size_t n, size_t nchan, size_t in_pitch,
                        sdrx_psk_state *states, uint8_t *out, size_t out_pitch, void *work, void *stream);
+/*
+ * sdrx_psk_demod_dev for callers that cannot allocate and bring no workspace: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same arguments and results as
+ * sdrx_psk_demod_dev minus `work`: the matched-filter output and the filter's zero-history rows live in a static
+ * device array of SDRX_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds until the process ends.  The
+ * call makes no hipMalloc / hipFree (neither does any routine it calls; the array's per-device address is looked up
+ * by sdrx_init, or by the first call on a device).  Shapes whose workspace -- sdrx_psk_work_bytes(n, nchan) -- exceeds
+ * sdrx_psk_demod_noalloc_max_bytes() are rejected with SDRX_EUNSUPPORTED.  Every call on a GPU shares that GPU's
+ * array: calls that overlap on one GPU (two streams, two threads) race; serialise them or use sdrx_psk_demod_dev.
+ */
+#define SDRX_NOALLOC_SCRATCH_BYTES (16u << 20)
+size_t sdrx_psk_demod_noalloc_max_bytes(void);
+int sdrx_psk_demod_noalloc_dev(int kind, const double *iq, size_t n, size_t nchan, size_t in_pitch,
+                               sdrx_psk_state *states, uint8_t *out, size_t out_pitch, void *stream);
 /* stage entry points (the reference keeps every stage public and unit-tested) */
 int sdrx_psk_matched_filter_dev(const double *iq, size_t n, size_t nchan, size_t in_pitch, double *mf_iq,
                                 size_t mf_pitch, void *stream); /* decode_pulseShape: n -> n/4 interleaved */

@@ -84,6 +84,8 @@ SIGNATURES = {
     "sdrx_psk_state_init_qpsk": (None, [C.POINTER(PskState), _vp, _sz]),
     "sdrx_psk_work_bytes": (_sz, [_sz, _sz]),
     "sdrx_psk_demod_dev": (C.c_int, [C.c_int, _vp, _sz, _sz, _sz, _vp, _vp, _sz, _vp, _vp]),
+    "sdrx_psk_demod_noalloc_max_bytes": (_sz, []),
+    "sdrx_psk_demod_noalloc_dev": (C.c_int, [C.c_int, _vp, _sz, _sz, _sz, _vp, _vp, _sz, _vp]),
     "sdrx_psk_matched_filter_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp, _sz, _vp]),
     "sdrx_psk_loops_dev": (C.c_int, [C.c_int, _vp, _sz, _sz, _sz, _vp, _vp, _sz, C.c_int, C.c_int, _vp]),
     "sdrx_psk_ambiguity_dev": (C.c_int, [C.c_int, _vp, _sz, _sz, _sz, _vp, _vp]),

@@ -138,6 +138,8 @@ static void staged_copy(void *dst, const void *src, size_t bytes)
 
 using namespace sdrx;
 
+static int noalloc_setup(unsigned char **out); // below, beside the static scratch array
+
 // =========================================================================== library
 
 extern "C" int sdrx_init(int device)
@@ -146,7 +148,7 @@ extern "C" int sdrx_init(int device)
     SDRX_HIP(hipFree(nullptr));
     (void)am_threshold_sq();
     (void)tuning();
-    return SDRX_OK;
+    return noalloc_setup(nullptr); // the static scratch's address on this device
 }
 
 extern "C" int sdrx_device_count(void)
@@ -340,6 +342,81 @@ extern "C" int sdrx_psk_demod_dev(int kind, const double *iq, size_t n, size_t n
     double *zst = (double *)(w + align256(nchan * m * 2 * sizeof(double)));
     double *dst = (double *)((unsigned char *)zst + align256(nchan * MF_STATE * sizeof(double)));
     int rc = mf_launch(iq, n, nchan, in_pitch, mf, m, zst, dst, s);
+    if (rc) return rc;
+    rc = launch_psk_loops(kind, mf, m, nchan, m, states, out, out_pitch, 1, 1, s);
+    if (rc) return rc;
+    return launch_psk_ambiguity(kind, out, (m + 1) / 2, nchan, out_pitch, states, s);
+}
+
+// ---- the one entry point that allocates nothing (no counterpart in the reference; see include/sdrx.h)
+//
+// sdrx_psk_demod_dev with its `work` argument replaced by a file-scope device array.  Layout of the array:
+//   [0, NOALLOC_OFFS_BYTES)   the matched filter's window-offset table (written by a kernel on the call's stream)
+//   [NOALLOC_OFFS_BYTES, ...) the workspace sdrx_psk_demod_dev takes: matched-filter output, zero and dummy state rows
+// `scratch` below is a host-side stand-in for the symbol, not a device address: every use goes through the
+// per-device pointer hipGetSymbolAddress returns (each GPU holds its own copy of the array at its own address).
+static __device__ __align__(256) unsigned char scratch[SDRX_NOALLOC_SCRATCH_BYTES];
+static const size_t NOALLOC_OFFS_INTS = 1024, NOALLOC_OFFS_BYTES = NOALLOC_OFFS_INTS * sizeof(int);
+static const int NOALLOC_MAX_DEVICES = 64;
+static std::mutex g_scratch_mu;
+static unsigned char *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// Once per device, with that device current: from sdrx_init(), else from the entry point's first call there.
+static int noalloc_setup(unsigned char **out)
+{
+    int dev = 0;
+    SDRX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
+        set_error("device %d beyond the %d the library keeps a scratch pointer for", dev, NOALLOC_MAX_DEVICES);
+        return SDRX_EUNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        unsigned char *p = nullptr;
+        SDRX_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        if (!p) {
+            set_error("hipGetSymbolAddress(scratch) returned a null address on device %d", dev);
+            return SDRX_EHIP;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    if (out) *out = g_scratch_ptr[dev];
+    return SDRX_OK;
+}
+
+extern "C" size_t sdrx_psk_demod_noalloc_max_bytes(void) { return SDRX_NOALLOC_SCRATCH_BYTES - NOALLOC_OFFS_BYTES; }
+
+extern "C" int sdrx_psk_demod_noalloc_dev(int kind, const double *iq, size_t n, size_t nchan, size_t in_pitch,
+                                          sdrx_psk_state *states, uint8_t *out, size_t out_pitch, void *stream)
+{
+    if (!iq || !states || !out) {
+        set_error("sdrx_psk_demod_noalloc_dev: null pointer");
+        return SDRX_EINVAL;
+    }
+    if (kind != SDRX_BPSK && kind != SDRX_QPSK) {
+        set_error("sdrx_psk_demod_noalloc_dev: kind %d", kind);
+        return SDRX_EINVAL;
+    }
+    // nchan * (n / 4) * 16 must not wrap before it is compared with the limit
+    const size_t limit = sdrx_psk_demod_noalloc_max_bytes();
+    if (nchan > limit || n / 4 > limit || (nchan && (n / 4) > limit / nchan) || sdrx_psk_work_bytes(n, nchan) > limit) {
+        set_error("sdrx_psk_demod_noalloc_dev: %zu channels x %zu samples need a workspace beyond the static scratch's "
+                  "%zu bytes (use sdrx_psk_demod_dev with a caller workspace)", nchan, n, limit);
+        return SDRX_EUNSUPPORTED;
+    }
+    unsigned char *base = nullptr;
+    int rc = noalloc_setup(&base);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t m = n / 4;
+    int *offs = (int *)base;
+    unsigned char *w = base + NOALLOC_OFFS_BYTES;
+    double *mf = (double *)w;
+    double *zst = (double *)(w + align256(nchan * m * 2 * sizeof(double)));
+    double *dst = (double *)((unsigned char *)zst + align256(nchan * MF_STATE * sizeof(double)));
+    // everything the kernels expect to start at zero is cleared by mf_launch (the zero-history rows); the rest of the
+    // array keeps the last call's contents and is overwritten before it is read
+    rc = mf_launch(iq, n, nchan, in_pitch, mf, m, zst, dst, s, offs, (unsigned)NOALLOC_OFFS_INTS);
     if (rc) return rc;
     rc = launch_psk_loops(kind, mf, m, nchan, m, states, out, out_pitch, 1, 1, s);
     if (rc) return rc;
