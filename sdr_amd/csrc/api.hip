@@ -159,6 +159,7 @@ extern "C" int sdrx_device_count(void)
 }
 
 extern "C" const char *sdrx_last_error(void) { return g_err; }
+extern "C" const char *sdrx_version(void) { return "sdrx 0.2 (gfx950)"; }
 
 extern "C" int sdrx_tune(const char *name, const char *value)
 {
@@ -185,21 +186,29 @@ extern "C" int sdrx_tune(const char *name, const char *value)
 
 extern "C" const char *sdrx_last_kernel(void)
 {
-    static thread_local char buf[160];
-    const LastKernel &k = t_last_kernel;
+    static thread_local char buf[512];
     static const char *const lay[] = {"REAL", "IQ_SPLIT", "IQ_INTERLEAVED", "IQ_U8"};
     static const char *const epi[] = {"EPI_STORE", "EPI_AM", "EPI_DISC"};
-    if (strcmp(k.family, "fir_systolic_kernel") == 0)
-        snprintf(buf, sizeof(buf), "fir_systolic_kernel<D=%d, %s, %s%s>", k.a, lay[k.b & 3], epi[k.c % 3], k.d ? ", fma" : "");
-    else if (strcmp(k.family, "fir_tile_kernel") == 0)
-        snprintf(buf, sizeof(buf), "fir_tile_kernel<R=%d, %s, %s%s>", k.a, lay[k.b & 3], epi[k.c % 3], k.d ? ", fma" : "");
-    else if (strncmp(k.family, "psk_loops", 9) == 0)
-        snprintf(buf, sizeof(buf), "%s<%s>", k.family, k.a == SDRX_BPSK ? "BPSK" : "QPSK");
-    else
-        snprintf(buf, sizeof(buf), "%s", k.family);
+    const LastKernel &l = t_last_kernel;
+    size_t at = 0;
+    buf[0] = 0;
+    for (int i = 0; i < l.n && at < sizeof(buf) - 1; i++) {
+        const KernelNote &k = l.k[i];
+        char one[160];
+        if (strcmp(k.family, "fir_systolic_kernel") == 0)
+            snprintf(one, sizeof(one), "fir_systolic_kernel<D=%d, %s, %s%s>", k.a, lay[k.b & 3], epi[k.c % 3], k.d ? ", fma" : "");
+        else if (strcmp(k.family, "fir_tile_kernel") == 0)
+            snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s%s>", k.a, lay[k.b & 3], epi[k.c % 3], k.d ? ", fma" : "");
+        else if (strncmp(k.family, "psk_loops", 9) == 0)
+            snprintf(one, sizeof(one), "%s<%s>", k.family, k.a == SDRX_BPSK ? "BPSK" : "QPSK");
+        else if (strcmp(k.family, "psk_ambiguity_kernel") == 0)
+            snprintf(one, sizeof(one), "psk_ambiguity_kernel<%d>", k.b);
+        else
+            snprintf(one, sizeof(one), "%s", k.family);
+        at += (size_t)snprintf(buf + at, sizeof(buf) - at, "%s%s", i ? " -> " : "", one);
+    }
     return buf;
 }
-extern "C" const char *sdrx_version(void) { return "sdrx 0.1 (gfx950)"; }
 
 // =========================================================================== 1. device layer
 
@@ -335,6 +344,7 @@ extern "C" int sdrx_psk_demod_dev(int kind, const double *iq, size_t n, size_t n
         set_error("sdrx_psk_demod_dev: null pointer");
         return SDRX_EINVAL;
     }
+    KernelChain kc;
     hipStream_t s = (hipStream_t)stream;
     const size_t m = n / 4;
     unsigned char *w = (unsigned char *)work;
@@ -407,6 +417,7 @@ extern "C" int sdrx_psk_demod_noalloc_dev(int kind, const double *iq, size_t n, 
     unsigned char *base = nullptr;
     int rc = noalloc_setup(&base);
     if (rc) return rc;
+    KernelChain kc;
     hipStream_t s = (hipStream_t)stream;
     const size_t m = n / 4;
     int *offs = (int *)base;

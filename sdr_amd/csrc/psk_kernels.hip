@@ -324,7 +324,7 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
             hipLaunchKernelGGL(psk_loops_split_kernel<SDRX_QPSK>, dim3((unsigned)blocks), dim3(128), 0, s,
                                (const double2 *)mf_iq, m, nchan, mf_pitch, states, decisions, out_pitch);
         SDRX_HIP(hipGetLastError());
-        t_last_kernel = {"psk_loops_split_kernel", kind, 0, 0, 0};
+        note_kernel("psk_loops_split_kernel", kind, 0, 0, 0);
         return SDRX_OK;
     }
     typedef void (*fn_t)(double2 *, size_t, size_t, size_t, sdrx_psk_state *, uint8_t *, size_t);
@@ -338,7 +338,7 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64), 0, s, (double2 *)mf_iq, m, nchan, mf_pitch, states, decisions,
                        out_pitch);
     SDRX_HIP(hipGetLastError());
-    t_last_kernel = {"psk_loops_kernel", kind, run_timing, run_phase, 0};
+    note_kernel("psk_loops_kernel", kind, run_timing, run_phase, 0);
     return SDRX_OK;
 }
 
@@ -480,6 +480,7 @@ int launch_psk_ambiguity(int kind, uint8_t *decisions, size_t m, size_t nchan, s
         hipLaunchKernelGGL(psk_ambiguity_kernel<256>, dim3((unsigned)nchan), dim3(256), 0, s, kind, decisions, m, out_pitch,
                            states, (unsigned long long *)nullptr, (size_t)0);
     SDRX_HIP(hipGetLastError());
+    note_kernel("psk_ambiguity_kernel", kind, m <= 2048 ? 64 : 256);
     return SDRX_OK;
 }
 

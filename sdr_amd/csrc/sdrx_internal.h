@@ -45,12 +45,28 @@ struct Tuning {
 };
 Tuning &tuning();
 
-// What the launchers picked last on this thread (sdrx_last_kernel(): bench.py's roofline.kernel).
+// What the launchers picked last on this thread (sdrx_last_kernel(): bench.py's roofline.kernel).  An entry point
+// that launches a chain of kernels opens a KernelChain; its launches are then listed in order.
+struct KernelNote {
+    const char *family; // "fir_systolic_kernel", "fir_tile_kernel", "fir_mfma_kernel<NB=4>", "psk_loops_split_kernel", ...
+    int a, b, c, d;     // family-specific template arguments
+};
 struct LastKernel {
-    const char *family = "";  // "fir_systolic_kernel", "fir_tile_kernel", "fir_mfma_kernel", "psk_loops_split_kernel", ...
-    int a = 0, b = 0, c = 0, d = 0; // family-specific template arguments
+    KernelNote k[4];
+    int n = 0;
+    bool chain = false;
 };
 extern thread_local LastKernel t_last_kernel;
+inline void note_kernel(const char *family, int a = 0, int b = 0, int c = 0, int d = 0)
+{
+    LastKernel &l = t_last_kernel;
+    if (!l.chain) l.n = 0;
+    if (l.n < 4) l.k[l.n++] = KernelNote{family, a, b, c, d};
+}
+struct KernelChain {
+    KernelChain() { t_last_kernel.n = 0; t_last_kernel.chain = true; }
+    ~KernelChain() { t_last_kernel.chain = false; }
+};
 
 // launchers implemented in fir_kernels.hip
 enum FirEpilogue { EPI_STORE = 0, EPI_AM = 1, EPI_DISC = 2 };
