@@ -176,7 +176,9 @@ int sdrx_deframe_dev(const uint8_t *bits, size_t n, size_t nchan, size_t in_pitc
 
 /* The reference's DigitalSignalProcessing primitives on `nchan` rows of n doubles (row c at c * pitch), in place or
  * x -> y; every row is computed in the reference's operation order (bit-identical to the CPU classes).
- *   SDRX_IIR_DC_BLOCK   DC_Filter::update (DC_Filter.cpp:12-19), coef = {R}; restarts at every call like the reference
+ *   SDRX_IIR_DC_BLOCK   DC_Filter::update (DC_Filter.cpp:12-19), coef = {R}; restarts at every call like the reference;
+ *                       called in place (y == x) it is the reference's aliased call: input[i-1] is read after
+ *                       output[i-1] overwrote it, y(n) = x(n) - y(n-1) + R*y(n-1)
  *   SDRX_IIR_LOWPASS    LowPassFilter::update per sample (LowPassFilter.cpp:13-16), coef = {ePow = sdrx_lowpass1_coef()},
  *                       state[4c] = `output`
  *   SDRX_IIR_NOTCH      NotchFilter::filter (NotchFilter.cpp:18-37), coef = sdrx_notch_design(); state[4c..4c+3] =
@@ -207,6 +209,26 @@ int sdrx_fifth_order_decimate_block_dev(double *iq, size_t n_points, size_t ncha
  * n a power of two <= SDRX_FFT_MAX; twiddles from sdrx_math.h's sincos (<= 1e-12 of the libm build). */
 #define SDRX_FFT_MAX 4096
 int sdrx_fft_dev(double *iq, size_t n, size_t nchan, size_t pitch, void *stream);
+
+/* AM<T>::modulate (AM.h:41-54) = raw_upsample (Resample.h:15-27) over nchan bit streams (one byte per bit): every bit
+ * repeated floor(len_mod / len) times as a double; outputs past len * floor(len_mod / len) are left untouched. */
+int sdrx_am_modulate_dev(const uint8_t *bits, size_t len, size_t nchan, size_t in_pitch, double *out_real, size_t len_mod,
+                         size_t out_pitch, void *stream);
+/* FM<T>::modulate (FM.h:44-74) over nchan bit streams: bit != 0 copies w_mark[0 .. spb), else w_space (device tables of
+ * spb doubles, e.g. from sdrx_fm_tables(..., for_modulator = 1)) to out_real[i * spb ...]. */
+int sdrx_fm_modulate_dev(const uint8_t *bits, size_t len, size_t nchan, size_t in_pitch, const double *w_mark,
+                         const double *w_space, size_t spb, double *out_real, size_t out_pitch, void *stream);
+/* FM<T>::convolve (FM.h:83-108 with the `ds` parameter of the repair): for k = 0, 1, ... while
+ * i = ds-1 + k*ds < len1: out[k] += sum_{j=0}^{len2-1} x[i-j] * w[len2-1-j] (x = 0 before its start), j ascending. */
+int sdrx_fm_convolve_dev(const double *x, size_t len1, const double *w, size_t len2, double *out, size_t ds, void *stream);
+/* The mark / space cosine tables as the reference builds them on the host (libm): for_modulator = 1: FM.h:47-57
+ * (sqrt(2)/sqrt(n) * cos(2 PI f dt i)); 0: FM.h:127-131 / fm.cu:62-68 (sqrt(2/n) * cos(2 PI f i dt)). */
+void sdrx_fm_tables(double sample_rate, double mark, double space, size_t n, int for_modulator, double *w_mark,
+                    double *w_space);
+/* BPSK::RRC_COEFF / QPSK::RRC_COEFF (BPSK.cpp:18-50, QPSK.cpp:32-64): the 129 root-raised-cosine taps (host table). */
+const double *sdrx_rrc_coeff(void);
+/* QPSK::DEFAULT_UNIQUE_WORD (QPSK.h:30, QPSK.cpp:20-28): 64 symbols, the constructor's default argument. */
+const double *sdrx_qpsk_default_unique_word(void);
 
 /* PSK loop state of one channel: the reference's public loop structs (BPSK.h:130-276) flattened. */
 typedef struct sdrx_psk_state {
@@ -282,6 +304,8 @@ size_t sdrx_fm_demodulate(double rx_rate, double mark, double space, const doubl
                           size_t ds);                                                             /* FM.h:112-148 */
 void sdrx_fm_modulate(double tx_rate, double mark, double space, const uint8_t *bits, size_t len,
                       double *out_real, size_t spb);                                              /* FM.h:44-74 */
+void sdrx_fm_convolve(const double *input1, size_t length1, const double *input2, size_t length2, double *output,
+                      size_t length_output, size_t ds);                                           /* FM.h:83-108 */
 /* Chains of BASELINE configs 1 and 2 on host buffers (state in the two Filter-like objects). */
 typedef struct sdrx_chain sdrx_chain_t;
 sdrx_chain_t *sdrx_chain_create(const double *taps, int num_taps, unsigned decim);
@@ -304,6 +328,11 @@ void sdrx_psk_set_state(sdrx_psk_t *p, const sdrx_psk_state *in);
  * out[n/8] decisions as doubles (real part of the output block; imag is 0).  Returns the count.
  * hits (may be NULL, capacity max_hits): UW hits as (position << 3 | code) for the "Phase ..." prints. */
 size_t sdrx_psk_demodulate(sdrx_psk_t *p, const double *iq, size_t n, double *out, uint64_t *hits, size_t max_hits);
+/* BPSK::demodulate(Complex_Array&, uint8_t*, n, downsample, real_plot, imag_plot) (BPSK.cpp:178-211) after its
+ * decimateComplexArray (done by the caller: include/sdrx/Resample.h): bits out, the timing loop's n/4 output samples
+ * to plot_re / plot_im (either may be NULL).  Returns the number of bits. */
+size_t sdrx_psk_demodulate_plot(sdrx_psk_t *p, const double *iq, size_t n, uint8_t *out_bits, double *plot_re,
+                                double *plot_im, uint64_t *hits, size_t max_hits);
 /* stage methods on host buffers (BPSK.cpp:213-487 / QPSK.cpp:222-509) */
 size_t sdrx_psk_decode_pulse_shape(sdrx_psk_t *p, const double *iq, size_t n, double *re, double *im);
 void sdrx_psk_timing(sdrx_psk_t *p, double *re, double *im, size_t n);

@@ -2,6 +2,8 @@
 #ifndef RADIONODE_AM_H
 #define RADIONODE_AM_H
 
+#include "Resample.h"            // AM.h:8
+#include "SafeBufferPoolQueue.h" // AM.h:7
 #include "common.h"
 
 template <class data_type> class AM {

@@ -4,10 +4,15 @@
 #ifndef RADIONODE_BPSK_H
 #define RADIONODE_BPSK_H
 
+#include "Resample.h"
 #include "psk_common.h"
 
 class BPSK : public sdrx_psk_dropin {
   public:
+    static const RADIO_DATA_TYPE LUT_REAL[2];      // BPSK.h:23, BPSK.cpp:14
+    static const RADIO_DATA_TYPE LUT_180[2];       // BPSK.h:24, BPSK.cpp:15
+    static const RADIO_DATA_TYPE (&RRC_COEFF)[129]; // BPSK.h:25, BPSK.cpp:18-50: the library's one host table
+
     enum PhaseAmbiguity { Ambiguity_0 = 0, Ambiguity_180 = 1 };
 
     BPSK(uint64_t UniqueWord = 0x4E, size_t UniqueWordLength = 8) // BPSK.cpp:52-90
@@ -37,6 +42,19 @@ class BPSK : public sdrx_psk_dropin {
             output->points[i].imag(0);
             output->n_points++;
         }
+    }
+    // BPSK.cpp:178-211: the overload the receiver is written to call (rtlsdr_receiver.cpp:2096)
+    size_t demodulate(Complex_Array &input, uint8_t *output, size_t number_of_points, size_t downsample,
+                      RADIO_DATA_TYPE *real_plot_data, RADIO_DATA_TYPE *imag_plot_data)
+    {
+        const size_t points = decimateComplexArray(input, number_of_points, downsample);
+        std::vector<uint64_t> hits(4096);
+        sync_in();
+        const size_t m = sdrx_psk_demodulate_plot(m_h, reinterpret_cast<const double *>(&input[0]), points, output,
+                                                  real_plot_data, imag_plot_data, hits.data(), hits.size());
+        sync_out();
+        print_hits(hits);
+        return m;
     }
     size_t decode_pulseShape(BBP_Block *input, RADIO_DATA_TYPE *real, RADIO_DATA_TYPE *imag) // BPSK.cpp:257-300
     {
@@ -105,5 +123,9 @@ class BPSK : public sdrx_psk_dropin {
             std::cout << ((hits[i] & 7) == 0 ? "Phase 0" : "Phase 180") << std::endl;
     }
 };
+
+inline const RADIO_DATA_TYPE BPSK::LUT_REAL[2] = {1, -1};
+inline const RADIO_DATA_TYPE BPSK::LUT_180[2] = {1, 0};
+inline const RADIO_DATA_TYPE (&BPSK::RRC_COEFF)[129] = *reinterpret_cast<const RADIO_DATA_TYPE (*)[129]>(sdrx_rrc_coeff());
 
 #endif

@@ -2,13 +2,23 @@
 #ifndef RADIONODE_QPSK_H
 #define RADIONODE_QPSK_H
 
+#include "Resample.h"
 #include "psk_common.h"
 
 class QPSK : public sdrx_psk_dropin {
   public:
+    static const RADIO_DATA_TYPE LUT_REAL[4];      // QPSK.h:23-28, QPSK.cpp:14-19
+    static const RADIO_DATA_TYPE LUT_IMAG[4];
+    static const RADIO_DATA_TYPE LUT_REAL___0[4];
+    static const RADIO_DATA_TYPE LUT_REAL__90[4];
+    static const RADIO_DATA_TYPE LUT_REAL_180[4];
+    static const RADIO_DATA_TYPE LUT_REAL_270[4];
+    static const RADIO_DATA_TYPE (&RRC_COEFF)[129];         // QPSK.h:29, QPSK.cpp:32-64: the library's one host table
+    static const RADIO_DATA_TYPE (&DEFAULT_UNIQUE_WORD)[64]; // QPSK.h:30, QPSK.cpp:20-28
+
     enum PhaseAmbiguity { Ambiguity_0 = 0, Ambiguity_180 = 1 };
 
-    QPSK(const RADIO_DATA_TYPE *UniqueWord = nullptr /* DEFAULT_UNIQUE_WORD, QPSK.cpp:20-28 */, size_t UniqueWordLength = 16)
+    QPSK(const RADIO_DATA_TYPE *UniqueWord = DEFAULT_UNIQUE_WORD, size_t UniqueWordLength = 16) // QPSK.h:43
         : sdrx_psk_dropin(SDRX_QPSK, 0, UniqueWord, UniqueWordLength), m_RealData(nullptr), m_ImagData(nullptr), m_length(0),
           m_phase_ambiguity_cc_000(10, 5, 5), m_phase_ambiguity_cc_090(10, 5, 5), m_phase_ambiguity_cc_180(10, 5, 5),
           m_phase_ambiguity_cc_270(10, 5, 5)
@@ -121,5 +131,15 @@ class QPSK : public sdrx_psk_dropin {
         else if (m_phase_ambiguity_cc_270.high_confidence()) std::cout << "270 Degree Phase Detected" << std::endl;
     }
 };
+
+inline const RADIO_DATA_TYPE QPSK::LUT_REAL[4] = {1, -1, 1, -1};
+inline const RADIO_DATA_TYPE QPSK::LUT_IMAG[4] = {1, 1, -1, -1};
+inline const RADIO_DATA_TYPE QPSK::LUT_REAL___0[4] = {0, 1, 2, 3};
+inline const RADIO_DATA_TYPE QPSK::LUT_REAL__90[4] = {2, 0, 3, 1};
+inline const RADIO_DATA_TYPE QPSK::LUT_REAL_180[4] = {3, 2, 1, 0};
+inline const RADIO_DATA_TYPE QPSK::LUT_REAL_270[4] = {1, 3, 0, 2};
+inline const RADIO_DATA_TYPE (&QPSK::RRC_COEFF)[129] = *reinterpret_cast<const RADIO_DATA_TYPE (*)[129]>(sdrx_rrc_coeff());
+inline const RADIO_DATA_TYPE (&QPSK::DEFAULT_UNIQUE_WORD)[64] =
+    *reinterpret_cast<const RADIO_DATA_TYPE (*)[64]>(sdrx_qpsk_default_unique_word());
 
 #endif

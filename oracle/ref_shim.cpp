@@ -17,6 +17,10 @@
 #include <streams/QPSK.h>
 #include <DigitalSignalProcessing/Resample.h>
 #include <common/BBP_Block.h>
+#include <common/Baseband_Stream.h>
+#include <common/SafeBufferPoolQueue.h>
+#include <condition_variable>
+#include <mutex>
 #include <common/RingBuffer.h>
 #include <common/confidence_counter.h>
 #include <cmath>
@@ -66,6 +70,60 @@ size_t ref_upsample_fill_w_zeros(double *in, size_t in_len, double *out, size_t 
     return upsample_fill_w_zeros(in, in_len, out, out_len, ratio);
 }
 
+size_t ref_raw_upsample(double *in, size_t in_len, double *out, size_t out_len, double ratio)
+{
+    return raw_upsample<RADIO_DATA_TYPE>(in, in_len, out, out_len, ratio);
+}
+size_t ref_upsample(double *in, size_t in_len, double *out, size_t out_len, double ratio)
+{
+    return upsample(in, in_len, out, out_len, ratio);
+}
+// decimate(BBP_Block*): iq = interleaved complex of n_points points, in place; returns block->n_points afterwards
+size_t ref_decimate_block(double *iq, size_t n_points, size_t by)
+{
+    BBP_Block b(n_points ? n_points : 1);
+    for (size_t i = 0; i < n_points; i++) b.points[i] = Complex(iq[2 * i], iq[2 * i + 1]);
+    b.n_points = n_points;
+    decimate(&b, by);
+    for (size_t i = 0; i < n_points; i++) { iq[2 * i] = b.points[i].real(); iq[2 * i + 1] = b.points[i].imag(); }
+    return b.n_points;
+}
+size_t ref_decimate_complex(double *iq, size_t length, size_t by)
+{
+    Complex_Array a(Complex(0, 0), length ? length : 1);
+    for (size_t i = 0; i < length; i++) a[i] = Complex(iq[2 * i], iq[2 * i + 1]);
+    const size_t r = decimateComplexArray(a, length, by);
+    for (size_t i = 0; i < length; i++) { iq[2 * i] = a[i].real(); iq[2 * i + 1] = a[i].imag(); }
+    return r;
+}
+
+// ---- Baseband_Stream::load_buffer / load_buffer_and_rotate90 (Baseband_Stream.cpp:82-148): the byte -> sample
+// conversion, observed through the stream's own post callback.  n_bytes / 2 points must fit a default BBP_Block.
+size_t ref_baseband_load(const uint8_t *bytes, size_t n_bytes, int rotate90, double *re, double *im)
+{
+    SafeBufferPoolQueue pool(1);
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    size_t n_points = 0;
+    {
+        Baseband_Stream stream([&](BBP_Block *b) {
+            std::lock_guard<std::mutex> lk(mu);
+            n_points = b->n_points;
+            for (size_t i = 0; i < n_points; i++) { re[i] = b->points[i].real(); im[i] = b->points[i].imag(); }
+            done = true;
+            cv.notify_all();
+        }, &pool);
+        std::vector<char> buf(bytes, bytes + n_bytes); // rotate_90 works in place on the caller's bytes
+        buf.resize(n_bytes + 8);
+        if (rotate90) stream.load_buffer_and_rotate90(buf.data(), n_bytes);
+        else stream.load_buffer(buf.data(), n_bytes);
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+    } // ~Baseband_Stream joins its thread
+    return n_points;
+}
+
 // ---- BPSK ----
 void *ref_bpsk_new(uint64_t uw, size_t uw_len) { return new BPSK(uw, uw_len); }
 void ref_bpsk_free(void *h) { delete (BPSK *)h; }
@@ -91,6 +149,15 @@ size_t ref_bpsk_demodulate(void *h, const double *iq, size_t n, double *out_re, 
         if (out_im) out_im[i] = out.points[i].imag();
     }
     return out.n_points;
+}
+// overload 2 (BPSK.cpp:178-211): iq is modified in place by its decimateComplexArray, like the caller's valarray
+size_t ref_bpsk_demodulate2(void *h, double *iq, size_t n, size_t downsample, uint8_t *out, double *plot_re, double *plot_im)
+{
+    Complex_Array a(Complex(0, 0), n ? n : 1);
+    for (size_t i = 0; i < n; i++) a[i] = Complex(iq[2 * i], iq[2 * i + 1]);
+    const size_t m = ((BPSK *)h)->demodulate(a, out, n, downsample, plot_re, plot_im);
+    for (size_t i = 0; i < n; i++) { iq[2 * i] = a[i].real(); iq[2 * i + 1] = a[i].imag(); }
+    return m;
 }
 size_t ref_bpsk_decode_pulse_shape(void *h, const double *iq, size_t n, double *re, double *im)
 {

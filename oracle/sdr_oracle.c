@@ -9,9 +9,10 @@
  * Pinned by (a) every golden vector of the reference's own unit tests (tests/golden/reference_vectors.npz,
  * tests/test_oracle_golden.py), (b) the reference's classes compiled from /root/reference (oracle/_ref,
  * tests/test_oracle_vs_ref.py, build container only) and (c) vectors those compiled classes produced
- * (tests/golden/ref_fixtures.npz, tests/test_ref_fixtures.py, anywhere).  Parity unpinned (no reference vector and
- * not buildable here): the u8 conversions and rtl_fm's full_demod (orc_u8_*, orc_rtlfm_*), checked by their
- * defining properties only.
+ * (tests/golden/ref_fixtures.npz, tests/test_ref_fixtures.py, anywhere).  The u8 conversions (orc_u8_*) are pinned to
+ * the reference's Baseband_Stream::load_buffer / load_buffer_and_rotate90 the same two ways.  Parity unpinned (no
+ * reference vector and not buildable here: rtl_fm.c needs librtlsdr): rtl_fm's chain (orc_fm_discriminator*,
+ * orc_rtlfm_*), checked by its defining properties only.
  */
 #include "sdr_oracle.h"
 
@@ -240,6 +241,17 @@ size_t orc_fm_demodulate(double rx_rate, double mark, double space, const double
     return length;
 }
 
+void orc_fm_convolve(const double *input1, size_t length1, const double *input2, size_t length2, double *output,
+                     size_t ds)
+{
+    /* FM.h:83-108 with the 7th parameter `ds` of the repair */
+    double *real_data = (double *)calloc(length1 + 2 * length2 + 1, sizeof(double)); /* FM.h:85-86 */
+    for (size_t i = 0; i < length1; i++) real_data[i + length2] = input1[i];          /* FM.h:89-92 */
+    for (size_t i = ds - 1, oi = 0; i < length1; i += ds, oi++)                         /* FM.h:94 */
+        for (size_t j = 0; j < length2; j++) output[oi] += real_data[i + length2 - j] * input2[length2 - j - 1]; /* FM.h:98 */
+    free(real_data);
+}
+
 /* ----------------------------------------------------------- discriminator */
 
 static double orc_atan2(double y, double x, int math_mode)
@@ -429,6 +441,44 @@ size_t orc_upsample_fill_w_zeros(const double *in, size_t in_len, double *out, s
         for (int j = 0; j < (ceil(ratio) - 1) && oi < out_len && ii < in_len; j++) out[oi++] = 0;
     }
     return out_len;
+}
+
+size_t orc_upsample(const double *in, size_t in_len, double *out, size_t out_len, double ratio)
+{
+    (void)in_len; /* Resample.cpp:10: the parameter is commented out, the loop runs on out_length alone */
+    for (size_t oi = 0, ii = 0; oi < out_len; ii++) { /* Resample.cpp:12-19 */
+        out[oi++] = in[ii];
+        for (int j = 1; j < ceil(ratio) && oi < out_len; j++) out[oi++] = in[ii] + (ratio * j);
+    }
+    return out_len;
+}
+
+size_t orc_decimate_block(double *iq, size_t n_points, size_t by)
+{
+    size_t dst = 0, src = 0; /* Resample.cpp:38-48: points are {re, im} pairs; the first point is dropped */
+    while (src + by < n_points) {
+        src += by;
+        iq[2 * dst] = iq[2 * src];
+        iq[2 * dst + 1] = iq[2 * src + 1];
+        dst++;
+    }
+    return dst + 1; /* block->n_points */
+}
+
+size_t orc_decimate_complex(double *iq, size_t length, size_t by)
+{
+    size_t dst = 0, src = 0; /* Resample.cpp:50-70 */
+    while (src < length) {
+        iq[2 * dst] = iq[2 * src];
+        iq[2 * dst + 1] = iq[2 * src + 1];
+        src += by;
+        dst++;
+    }
+    for (size_t j = dst; j < length; j++) { /* (sic: index dst) */
+        iq[2 * dst] = 0;
+        iq[2 * dst + 1] = 0;
+    }
+    return dst;
 }
 
 /* ------------------------------------------------------------------ chains */

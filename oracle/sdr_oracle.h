@@ -90,6 +90,11 @@ size_t orc_rtlfm_full(const uint8_t *iq_u8, size_t n, int downsample, int rotate
 size_t orc_decimate(double *block, size_t length, size_t by);                                  /* Resample.h:33-52 */
 size_t orc_upsample_fill_w_zeros(const double *in, size_t in_len, double *out, size_t out_len, double ratio); /* Resample.cpp:24-36 */
 size_t orc_raw_upsample(const double *in, size_t in_len, double *out, size_t out_len, double ratio);          /* Resample.h:15-27 */
+size_t orc_upsample(const double *in, size_t in_len, double *out, size_t out_len, double ratio);              /* Resample.cpp:10-22 */
+size_t orc_decimate_block(double *iq, size_t n_points, size_t by);  /* decimate(BBP_Block*), Resample.cpp:38-48; returns n_points */
+size_t orc_decimate_complex(double *iq, size_t length, size_t by);  /* decimateComplexArray, Resample.cpp:50-70 */
+/* FM<T>::convolve, FM.h:83-108 (repaired): output[k] += ..., k = 0 .. while ds-1 + k*ds < length1 */
+void orc_fm_convolve(const double *input1, size_t length1, const double *input2, size_t length2, double *output, size_t ds);
 
 /* ---- composed chains (BASELINE configs 1 and 2/4) ---- */
 /* Filter::execute on I and on Q (state srI/srQ carried) then AM::demodulate(ds). */

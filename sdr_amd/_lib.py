@@ -80,6 +80,12 @@ SIGNATURES = {
     "sdrx_fifth_order_decimate_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, _vp]),
     "sdrx_fifth_order_decimate_block_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, C.POINTER(C.c_size_t), _vp]),
     "sdrx_fft_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp]),
+    "sdrx_am_modulate_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
+    "sdrx_fm_modulate_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "sdrx_fm_convolve_dev": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _sz, _vp]),
+    "sdrx_fm_tables": (None, [C.c_double, C.c_double, C.c_double, _sz, C.c_int, _vp, _vp]),
+    "sdrx_rrc_coeff": (C.POINTER(C.c_double), []),
+    "sdrx_qpsk_default_unique_word": (C.POINTER(C.c_double), []),
     "sdrx_psk_state_init_bpsk": (None, [C.POINTER(PskState), C.c_uint64, _sz]),
     "sdrx_psk_state_init_qpsk": (None, [C.POINTER(PskState), _vp, _sz]),
     "sdrx_psk_work_bytes": (_sz, [_sz, _sz]),
@@ -102,6 +108,7 @@ SIGNATURES = {
     "sdrx_am_modulate": (None, [_vp, _sz, _vp, _sz]),
     "sdrx_fm_demodulate": (_sz, [C.c_double, C.c_double, C.c_double, _vp, _vp, _sz, _sz]),
     "sdrx_fm_modulate": (None, [C.c_double, C.c_double, C.c_double, _vp, _sz, _vp, _sz]),
+    "sdrx_fm_convolve": (None, [_vp, _sz, _vp, _sz, _vp, _sz, _sz]),
     "sdrx_chain_create": (_vp, [_vp, C.c_int, C.c_uint]),
     "sdrx_chain_destroy": (None, [_vp]),
     "sdrx_chain_reset": (None, [_vp]),
@@ -114,6 +121,7 @@ SIGNATURES = {
     "sdrx_psk_get_state": (None, [_vp, C.POINTER(PskState)]),
     "sdrx_psk_set_state": (None, [_vp, C.POINTER(PskState)]),
     "sdrx_psk_demodulate": (_sz, [_vp, _vp, _sz, _vp, _vp, _sz]),
+    "sdrx_psk_demodulate_plot": (_sz, [_vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz]),
     "sdrx_psk_decode_pulse_shape": (_sz, [_vp, _vp, _sz, _vp, _vp]),
     "sdrx_psk_timing": (None, [_vp, _vp, _vp, _sz]),
     "sdrx_psk_phase_correction": (_sz, [_vp, _vp, _vp, _sz]),

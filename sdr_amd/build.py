@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "..", "build", "obj")
 LIB = os.path.join(HERE, "libsdrx.so")
-SOURCES = ["api.hip", "fir_kernels.hip", "fir_kernels_fma.hip", "fir_kernels_f32.hip", "fir_mfma.hip", "demod_kernels.hip", "psk_kernels.hip", "framer_kernels.hip", "dsp_kernels.hip"]
+SOURCES = ["api.hip", "fir_kernels.hip", "fir_kernels_fma.hip", "fir_kernels_f32.hip", "fir_mfma.hip", "demod_kernels.hip", "mod_kernels.hip", "psk_kernels.hip", "framer_kernels.hip", "dsp_kernels.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("sdrx_internal.h", "fir_common.h", "fir_impl.inc")] + [
     os.path.join(HERE, "..", "include", "sdrx.h"), os.path.join(HERE, "..", "include", "sdrx_math.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-comment"]

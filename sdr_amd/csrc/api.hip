@@ -257,6 +257,43 @@ extern "C" int sdrx_fm_demod_dev(const double *re, const double *w1, const doubl
     return launch_fm_demod(re, w1, w2, out, n, ds, (hipStream_t)stream);
 }
 
+extern "C" int sdrx_am_modulate_dev(const uint8_t *bits, size_t len, size_t nchan, size_t in_pitch, double *out_real,
+                                    size_t len_mod, size_t out_pitch, void *stream)
+{
+    return launch_am_modulate(bits, len, nchan, in_pitch, out_real, len_mod, out_pitch, (hipStream_t)stream);
+}
+extern "C" int sdrx_fm_modulate_dev(const uint8_t *bits, size_t len, size_t nchan, size_t in_pitch, const double *w_mark,
+                                    const double *w_space, size_t spb, double *out_real, size_t out_pitch, void *stream)
+{
+    return launch_fm_modulate(bits, len, nchan, in_pitch, w_mark, w_space, spb, out_real, out_pitch, (hipStream_t)stream);
+}
+extern "C" int sdrx_fm_convolve_dev(const double *x, size_t len1, const double *w, size_t len2, double *out, size_t ds,
+                                    void *stream)
+{
+    return launch_fm_convolve(x, len1, w, len2, out, ds, (hipStream_t)stream);
+}
+
+extern "C" void sdrx_fm_tables(double sample_rate, double mark, double space, size_t n, int for_modulator, double *w_mark,
+                               double *w_space)
+{
+    const double PI = 3.141592653589793238460; // Common_Deffinitions.h:14
+    const double delta_t = 1.0 / sample_rate;  // FM.h:46, FM.h:125
+    if (for_modulator) {                       // FM.h:47-57: RootRaised * cos(2 PI f delta_t i)
+        const double root_raised = sqrt(2) / sqrt(n);
+        for (size_t i = 0; i < n; i++) {
+            w_mark[i] = root_raised * cos(2.0 * PI * mark * delta_t * i);
+            w_space[i] = root_raised * cos(2.0 * PI * space * delta_t * i);
+        }
+    } else { // FM.h:127-131 (and fm.cu:62-68): sqrt(2/ds) * cos(2 PI f i delta_t) -- another operation order
+        for (size_t i = 0; i < n; i++) {
+            w_mark[i] = sqrt(2.0 / n) * cos(2.0 * PI * mark * i * delta_t);
+            w_space[i] = sqrt(2.0 / n) * cos(2.0 * PI * space * i * delta_t);
+        }
+    }
+}
+
+extern "C" const double *sdrx_rrc_coeff(void) { return RRC_COEFF; }
+
 // ---- PSK state (host arithmetic only: constructor logic of BPSK.cpp:52-90 / QPSK.cpp:66-120)
 static void psk_state_common(sdrx_psk_state *s, size_t uw_len)
 {
@@ -277,11 +314,15 @@ extern "C" void sdrx_psk_state_init_bpsk(sdrx_psk_state *s, uint64_t unique_word
     }
 }
 
+static const double QPSK_DEFAULT_UW[64] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                           0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                           0, 0, 0, 0, 3, 0, 2, 1, 0, 3, 2, 1, 2, 0, 1, 2, 3, 2, 2, 3}; // QPSK.cpp:20-28
+
+extern "C" const double *sdrx_qpsk_default_unique_word(void) { return QPSK_DEFAULT_UW; }
+
 extern "C" void sdrx_psk_state_init_qpsk(sdrx_psk_state *s, const double *uw64, size_t uw_len)
 {
-    static const double dflt[64] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                                    0, 0, 0, 0, 3, 0, 2, 1, 0, 3, 2, 1, 2, 0, 1, 2, 3, 2, 2, 3}; // QPSK.cpp:20-28
+    const double *dflt = QPSK_DEFAULT_UW;
     static const double l000[4] = {0, 1, 2, 3}, l090[4] = {2, 0, 3, 1}, l180[4] = {3, 2, 1, 0}, l270[4] = {1, 3, 0, 2};
     psk_state_common(s, uw_len);
     if (!uw64) uw64 = dflt;
@@ -655,27 +696,35 @@ extern "C" size_t sdrx_am_demodulate(const double *re, const double *im, uint8_t
 
 extern "C" void sdrx_am_modulate(const uint8_t *bits, size_t len, double *out_real, size_t len_mod)
 {
-    // AM.h:41-54 + raw_upsample (Resample.h:15-27): a bit-repeat copy, no arithmetic; done where the
-    // data lives (host buffers in, host buffers out).
+    // AM.h:41-54 + raw_upsample (Resample.h:15-27) on the device: bits up, the written prefix back.  Outputs past
+    // len * floor(len_mod / len) are not written by the reference and are not touched here.
     if (!bits || !out_real || len == 0) return;
-    const double ratio = (double)len_mod / (double)len;
-    const double rep = floor(ratio);
-    size_t oi = 0;
-    for (size_t ii = 0; oi < len_mod && ii < len; ii++)
-        for (int j = 0; (j < rep) && (oi < len_mod); j++) out_real[oi++] = (double)bits[ii];
+    const size_t rep = len_mod / len;
+    if (rep == 0) return;
+    const size_t n_write = len * rep;
+    HostCtx &c = t_ctx;
+    if (c.ready() || c.a.ensure(n_write * sizeof(double)) || c.c.ensure(len + 8)) {
+        printf("[HIP][sdrx_am_modulate] Error! %s\n", g_err);
+        return;
+    }
+    memcpy(c.c.host, bits, len);
+    bool ok = hipMemcpyAsync(c.c.dev, c.c.host, len, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              launch_am_modulate((const uint8_t *)c.c.dev, len, 1, len, (double *)c.a.dev, len_mod, n_write, c.stream) == SDRX_OK &&
+              hipMemcpyAsync(c.a.host, c.a.dev, n_write * sizeof(double), hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+              hipStreamSynchronize(c.stream) == hipSuccess;
+    if (!ok) {
+        printf("[HIP][sdrx_am_modulate] Error! %s\n", g_err);
+        return;
+    }
+    staged_copy(out_real, c.a.host, n_write * sizeof(double));
 }
 
 static void fm_waves(double rate, double mark, double space, size_t ds, std::vector<double> &w1,
                      std::vector<double> &w2)
 {
-    const double PI = 3.141592653589793238460; // Common_Deffinitions.h:14
-    const double delta_t = 1.0 / rate;         // FM.h:125
-    w1.resize(ds);
-    w2.resize(ds);
-    for (size_t i = 0; i < ds; i++) { // FM.h:127-131: host-built tables, as fm.cu:62-68 does
-        w1[i] = sqrt(2.0 / ds) * cos(2.0 * PI * mark * i * delta_t);
-        w2[i] = sqrt(2.0 / ds) * cos(2.0 * PI * space * i * delta_t);
-    }
+    w1.resize(ds ? ds : 1);
+    w2.resize(ds ? ds : 1);
+    sdrx_fm_tables(rate, mark, space, ds, 0, w1.data(), w2.data()); // FM.h:127-131, as fm.cu:62-68 does
 }
 
 extern "C" size_t sdrx_fm_demodulate(double rx_rate, double mark, double space, const double *re, uint8_t *out,
@@ -712,17 +761,59 @@ extern "C" size_t sdrx_fm_demodulate(double rx_rate, double mark, double space, 
 extern "C" void sdrx_fm_modulate(double tx_rate, double mark, double space, const uint8_t *bits, size_t len,
                                  double *out_real, size_t spb)
 {
-    // FM.h:44-74: two host cosine tables of spb samples and one memcpy per bit (2*spb cos calls in all).
-    if (!bits || !out_real || spb == 0) return;
-    const double PI = 3.141592653589793238460;
-    const double delta_t = 1.0 / tx_rate;
-    const double root_raised = sqrt(2) / sqrt(spb);
-    std::vector<double> w1(spb), w2(spb);
-    for (size_t i = 0; i < spb; i++) {
-        w1[i] = root_raised * cos(2.0 * PI * mark * delta_t * i);
-        w2[i] = root_raised * cos(2.0 * PI * space * delta_t * i);
+    // FM.h:44-74: the two cosine tables are host arithmetic (2*spb libm cos calls, as in the reference); the per-bit
+    // copies run on the device.
+    if (!bits || !out_real || spb == 0 || len == 0) return;
+    HostCtx &c = t_ctx;
+    const size_t n = len * spb, wbytes = spb * sizeof(double);
+    if (c.ready() || c.a.ensure(n * sizeof(double)) || c.b.ensure(2 * wbytes) || c.c.ensure(len + 8)) {
+        printf("[HIP][sdrx_fm_modulate] Error! %s\n", g_err);
+        return;
     }
-    for (size_t i = 0; i < len; i++) memcpy(&out_real[i * spb], bits[i] == 0 ? w2.data() : w1.data(), spb * sizeof(double));
+    sdrx_fm_tables(tx_rate, mark, space, spb, 1, (double *)c.b.host, (double *)c.b.host + spb);
+    memcpy(c.c.host, bits, len);
+    bool ok = hipMemcpyAsync(c.b.dev, c.b.host, 2 * wbytes, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              hipMemcpyAsync(c.c.dev, c.c.host, len, hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              launch_fm_modulate((const uint8_t *)c.c.dev, len, 1, len, (double *)c.b.dev, (double *)c.b.dev + spb, spb,
+                                 (double *)c.a.dev, n, c.stream) == SDRX_OK &&
+              hipMemcpyAsync(c.a.host, c.a.dev, n * sizeof(double), hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+              hipStreamSynchronize(c.stream) == hipSuccess;
+    if (!ok) {
+        printf("[HIP][sdrx_fm_modulate] Error! %s\n", g_err);
+        return;
+    }
+    staged_copy(out_real, c.a.host, n * sizeof(double));
+}
+
+extern "C" void sdrx_fm_convolve(const double *input1, size_t length1, const double *input2, size_t length2,
+                                 double *output, size_t length_output, size_t ds)
+{
+    // FM<T>::convolve (FM.h:83-108, repaired: 7th parameter ds).  lengthOutput is not used by the reference either:
+    // it writes output[0 .. number of i = ds-1, 2ds-1, ... < length1).
+    (void)length_output;
+    if (!input1 || !input2 || !output || ds == 0 || length1 < ds || length2 == 0) return;
+    const size_t n_out = (length1 - (ds - 1) + ds - 1) / ds;
+    HostCtx &c = t_ctx;
+    if (c.ready() || c.a.ensure(length1 * sizeof(double)) || c.b.ensure(length2 * sizeof(double)) ||
+        c.c.ensure(n_out * sizeof(double))) {
+        printf("[HIP][sdrx_fm_convolve] Error! %s\n", g_err);
+        return;
+    }
+    staged_copy(c.a.host, input1, length1 * sizeof(double));
+    memcpy(c.b.host, input2, length2 * sizeof(double));
+    memcpy(c.c.host, output, n_out * sizeof(double)); // the sums start from the outputs' prior values
+    bool ok = hipMemcpyAsync(c.a.dev, c.a.host, length1 * sizeof(double), hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              hipMemcpyAsync(c.b.dev, c.b.host, length2 * sizeof(double), hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              hipMemcpyAsync(c.c.dev, c.c.host, n_out * sizeof(double), hipMemcpyHostToDevice, c.stream) == hipSuccess &&
+              launch_fm_convolve((const double *)c.a.dev, length1, (const double *)c.b.dev, length2, (double *)c.c.dev, ds,
+                                 c.stream) == SDRX_OK &&
+              hipMemcpyAsync(c.c.host, c.c.dev, n_out * sizeof(double), hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+              hipStreamSynchronize(c.stream) == hipSuccess;
+    if (!ok) {
+        printf("[HIP][sdrx_fm_convolve] Error! %s\n", g_err);
+        return;
+    }
+    memcpy(output, c.c.host, n_out * sizeof(double));
 }
 
 // ---- FIR + demod chains on host buffers
@@ -998,6 +1089,49 @@ extern "C" size_t sdrx_psk_demodulate(sdrx_psk_t *p, const double *iq, size_t n,
         return 0;
     const uint8_t *d = (const uint8_t *)p->out.host;
     for (size_t i = 0; i < nd; i++) out[i] = (double)d[i]; // output block real part: BPSK.cpp:167-172
+    (void)psk_fetch_hits(p, hits, max_hits);
+    return nd;
+}
+
+extern "C" size_t sdrx_psk_demodulate_plot(sdrx_psk_t *p, const double *iq, size_t n, uint8_t *out_bits, double *plot_re,
+                                           double *plot_im, uint64_t *hits, size_t max_hits)
+{
+    // BPSK::demodulate(Complex_Array&, uint8_t*, n, downsample, plot bufs), BPSK.cpp:178-211, after its
+    // decimateComplexArray: matched filter, timing loop (its output also goes to the plot buffers), carrier loop + /2,
+    // ambiguity pass, bits = real > 0.5.  One upload, one synchronisation.
+    if (!p || !iq || !out_bits) return 0;
+    const size_t m = n / 4, nd = (m + 1) / 2;
+    if (m == 0) return 0;
+    const size_t in_bytes = n * 2 * sizeof(double), mf_bytes = m * 2 * sizeof(double);
+    if (p->in.ensure(in_bytes) || p->mid.ensure(sdrx_psk_work_bytes(n, 1)) || p->out.ensure(nd + 8) ||
+        p->hits.ensure(PSK_MAX_HITS * sizeof(uint64_t)))
+        return 0;
+    staged_copy(p->in.host, iq, in_bytes);
+    if (hipMemcpyAsync(p->in.dev, p->in.host, in_bytes, hipMemcpyHostToDevice, p->stream) != hipSuccess) return 0;
+    unsigned char *w = (unsigned char *)p->mid.dev;
+    double *mf = (double *)w;
+    double *zst = (double *)(w + align256(mf_bytes));
+    double *dst = (double *)((unsigned char *)zst + align256(MF_STATE * sizeof(double)));
+    if (mf_launch((double *)p->in.dev, n, 1, n, mf, m, zst, dst, p->stream) != SDRX_OK) return 0;
+    if (launch_psk_loops(p->kind, mf, m, 1, m, p->d_state, (uint8_t *)p->out.dev, nd, 1, 0, p->stream) != SDRX_OK) return 0;
+    if (hipMemcpyAsync(p->mid.host, mf, mf_bytes, hipMemcpyDeviceToHost, p->stream) != hipSuccess) return 0;
+    if (launch_psk_loops(p->kind, mf, m, 1, m, p->d_state, (uint8_t *)p->out.dev, nd, 0, 1, p->stream) != SDRX_OK) return 0;
+    if (launch_psk_ambiguity_hits(p->kind, (uint8_t *)p->out.dev, nd, 1, nd, p->d_state,
+                                  (unsigned long long *)p->hits.dev, PSK_MAX_HITS, p->stream) != SDRX_OK)
+        return 0;
+    if (hipMemcpyAsync(p->out.host, p->out.dev, nd, hipMemcpyDeviceToHost, p->stream) != hipSuccess ||
+        hipMemcpyAsync(p->hits.host, p->hits.dev, PSK_MAX_HITS * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream) !=
+            hipSuccess ||
+        hipStreamSynchronize(p->stream) != hipSuccess)
+        return 0;
+    const double *h = (const double *)p->mid.host;
+    if (plot_re)
+        for (size_t i = 0; i < m; i++) plot_re[i] = h[2 * i];
+    if (plot_im)
+        for (size_t i = 0; i < m; i++) plot_im[i] = h[2 * i + 1];
+    memcpy(out_bits, p->out.host, nd); // decisions are 0 / 1 (0..3 for QPSK): `real > 0.5 ? 1 : 0` of BPSK.cpp:203 for BPSK
+    if (p->kind == SDRX_QPSK)
+        for (size_t i = 0; i < nd; i++) out_bits[i] = out_bits[i] > 0 ? 1 : 0;
     (void)psk_fetch_hits(p, hits, max_hits);
     return nd;
 }

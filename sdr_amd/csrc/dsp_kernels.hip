@@ -46,8 +46,9 @@ template <int KIND> __device__ __forceinline__ double iir_first(double x, double
 
 template <int KIND> __device__ __forceinline__ double iir_step(double x, double (&s)[4], const IirCoef &k)
 {
-    if (KIND == K_DC) { // y(n) = x(n) - x(n-1) + R*y(n-1)
-        double y = x - s[0] + k.c[0] * s[1];
+    if (KIND == K_DC) { // y(n) = x(n) - x(n-1) + R*y(n-1); in place (c[1] != 0) input[i-1] has already been overwritten
+        const double xp = k.c[1] != 0.0 ? s[1] : s[0]; // by output[i-1] when the reference reads it (DC_Filter.cpp:18)
+        double y = x - xp + k.c[0] * s[1];
         s[0] = x, s[1] = y;
         return y;
     }
@@ -404,6 +405,7 @@ extern "C" int sdrx_iir_dev(int kind, const double *coef, const double *x, doubl
     }
     IirCoef k = {{0, 0, 0, 0, 0}};
     for (int j = 0; j < ncoef[kind]; j++) k.c[j] = coef[j];
+    if (kind == K_DC && (const double *)y == x) k.c[1] = 1.0; // aliased call: the reference's own in-place behaviour
     // rows per wave: the largest of 64 / 16 / 4 that still gives every SIMD of the part (1024) a wave
     int cw = nchan >= 64 * 1024 ? 64 : (nchan >= 16 * 1024 ? 16 : 4);
     if (const int v = tuning().iir_cw; v == 64 || v == 16 || v == 4) cw = v;

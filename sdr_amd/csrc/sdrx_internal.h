@@ -90,6 +90,13 @@ int launch_rtlfm_full(const sdrx_rtlfm_params *p, const uint8_t *iq, size_t n, s
                       const int32_t *st_in, int32_t *st_out, int32_t *post_state, int64_t *work, int16_t *pcm,
                       size_t out_pitch, hipStream_t s);
 
+// mod_kernels.hip
+int launch_am_modulate(const uint8_t *bits, size_t len, size_t nchan, size_t in_pitch, double *out, size_t len_mod,
+                       size_t out_pitch, hipStream_t s);
+int launch_fm_modulate(const uint8_t *bits, size_t len, size_t nchan, size_t in_pitch, const double *w_mark,
+                       const double *w_space, size_t spb, double *out, size_t out_pitch, hipStream_t s);
+int launch_fm_convolve(const double *x, size_t len1, const double *w, size_t len2, double *out, size_t ds, hipStream_t s);
+
 // framer_kernels.hip
 int launch_deframe(const uint8_t *bits, size_t n, size_t nchan, size_t in_pitch, int crc_enable, sdrx_frame_event *events,
                    uint8_t *payloads, size_t max_events, uint64_t *summary, hipStream_t s);

@@ -135,6 +135,43 @@ def fm_demod(re, w1, w2, out, ds):
                "sdrx_fm_demod_dev")
 
 
+def am_modulate(bits, out, len_mod=None):
+    """AM<T>::modulate over every row of bits (nchan, len) uint8 -> out (nchan, >= len_mod) float64."""
+    assert bits.dtype == torch.uint8 and bits.dim() == 2 and bits.is_contiguous()
+    assert out.dtype == torch.float64 and out.dim() == 2 and out.is_contiguous() and out.shape[0] == bits.shape[0]
+    len_mod = out.shape[1] if len_mod is None else int(len_mod)
+    _lib.check(_lib.lib().sdrx_am_modulate_dev(_ptr(bits), bits.shape[1], bits.shape[0], bits.shape[1], _ptr(out), len_mod,
+                                               out.shape[1], _stream()), "sdrx_am_modulate_dev")
+    return out
+
+
+def fm_tables(rate, mark, space, n, for_modulator):
+    """The reference's host-built cosine tables (FM.h:47-57 / FM.h:127-131) as numpy arrays."""
+    w1, w2 = np.zeros(max(n, 1)), np.zeros(max(n, 1))
+    _lib.lib().sdrx_fm_tables(float(rate), float(mark), float(space), int(n), int(bool(for_modulator)), w1.ctypes.data,
+                              w2.ctypes.data)
+    return w1[:n], w2[:n]
+
+
+def fm_modulate(bits, w_mark, w_space, out):
+    """FM<T>::modulate over every row of bits (nchan, len) uint8; w_mark / w_space: (spb,) float64 device tables;
+    out (nchan, >= len * spb) float64."""
+    assert bits.dtype == torch.uint8 and bits.dim() == 2 and bits.is_contiguous()
+    assert out.dtype == torch.float64 and out.dim() == 2 and out.is_contiguous() and out.shape[0] == bits.shape[0]
+    spb = w_mark.numel()
+    assert w_space.numel() == spb and out.shape[1] >= bits.shape[1] * spb
+    _lib.check(_lib.lib().sdrx_fm_modulate_dev(_ptr(bits), bits.shape[1], bits.shape[0], bits.shape[1], _ptr(w_mark),
+                                               _ptr(w_space), spb, _ptr(out), out.shape[1], _stream()), "sdrx_fm_modulate_dev")
+    return out
+
+
+def fm_convolve(x, w, out, ds):
+    """FM<T>::convolve (repaired): out[k] += sum_j x[(k+1)ds-1-j] * w[len2-1-j]; 1-D float64 device tensors."""
+    _lib.check(_lib.lib().sdrx_fm_convolve_dev(_ptr(x), x.numel(), _ptr(w), w.numel(), _ptr(out), int(ds), _stream()),
+               "sdrx_fm_convolve_dev")
+    return out
+
+
 class RtlFm:
     """rtl_fm's int16 chain (u8 bytes -> -127 -> boxcar decimate -> polar discriminant -> int16 pcm) over
     `nchan` independent byte streams, state carried like struct demod_state (rtl_fm.c:113-147)."""

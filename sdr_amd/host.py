@@ -101,6 +101,23 @@ class FM:
                                           int(number_of_points), int(ds))
 
 
+    def convolve(self, input1, length1, input2, length2, output, lengthOutput, ds):
+        """FM<T>::convolve with the `ds` parameter of the repair (FM.h:83-108): output[k] += ..., in place."""
+        self._L.sdrx_fm_convolve(_p(_f64(input1)), int(length1), _p(_f64(input2)), int(length2), _p(_f64(output)),
+                                 int(lengthOutput), int(ds))
+
+
+def decimateComplexArray(block, length, decimate_by=2):
+    """Resample.cpp:50-70 on an interleaved complex array (host index shuffle, as in include/sdrx/Resample.h): keeps
+    samples 0, by, 2*by, ...; clears only element [kept] after them.  Returns the kept count."""
+    z = block.reshape(-1, 2)
+    kept = -(-int(length) // int(decimate_by)) if length else 0
+    z[:kept] = z[0:length:decimate_by].copy()
+    if kept < length:
+        z[kept] = 0.0
+    return kept
+
+
 class _PSK:
     KIND = None
 
@@ -171,6 +188,19 @@ class BPSK(_PSK):
 
     def __init__(self, UniqueWord=0x4E, UniqueWordLength=8):
         super().__init__(UniqueWord, None, UniqueWordLength)
+
+    def demodulate_array(self, input_iq, output, number_of_points, downsample, real_plot_data=None, imag_plot_data=None):
+        """BPSK::demodulate(Complex_Array&, uint8_t*, n, downsample, real_plot, imag_plot), BPSK.cpp:178-211: the input is
+        decimated in place like the caller's valarray; returns the number of bits written to `output`."""
+        _f64(input_iq)
+        points = decimateComplexArray(input_iq, number_of_points, downsample)
+        hits = np.zeros(4096, dtype=np.uint64)
+        m = self._L.sdrx_psk_demodulate_plot(self._h, _p(input_iq), points, _p(_u8(output)),
+                                             None if real_plot_data is None else _p(_f64(real_plot_data)),
+                                             None if imag_plot_data is None else _p(_f64(imag_plot_data)), _p(hits), hits.size)
+        nh = self.state().n_hits
+        self.last_hits = [(int(h) >> 3, int(h) & 7) for h in hits[: min(nh, hits.size)]]
+        return m
 
     def modulate(self, data_in, length, modulated_real, length_modulated):
         _lib.check(self._L.sdrx_psk_modulate(_lib.BPSK, _p(_u8(data_in)), int(length), _p(_f64(modulated_real)), None,

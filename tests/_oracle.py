@@ -129,6 +129,16 @@ def lib():
     L.orc_decimate.restype = _sz
     L.orc_upsample_fill_w_zeros.argtypes = [_f64, _sz, _f64, _sz, C.c_double]
     L.orc_upsample_fill_w_zeros.restype = _sz
+    L.orc_raw_upsample.argtypes = [_f64, _sz, _f64, _sz, C.c_double]
+    L.orc_raw_upsample.restype = _sz
+    L.orc_upsample.argtypes = [_f64, _sz, _f64, _sz, C.c_double]
+    L.orc_upsample.restype = _sz
+    L.orc_decimate_block.argtypes = [_f64, _sz, _sz]
+    L.orc_decimate_block.restype = _sz
+    L.orc_decimate_complex.argtypes = [_f64, _sz, _sz]
+    L.orc_decimate_complex.restype = _sz
+    L.orc_fm_convolve.argtypes = [_f64, _sz, _f64, _sz, _f64, _sz]
+    L.orc_fm_convolve.restype = None
     L.orc_chain_fir_am.argtypes = [_f64, C.c_int, _f64, _f64, _f64, _f64, _sz, _sz, _u8]
     L.orc_chain_fir_am.restype = _sz
     L.orc_chain_fir_decim_disc.argtypes = [_f64, C.c_int, _f64, _f64, _f64, _f64, _f64, _sz, _sz, _f64, C.c_int]
@@ -342,6 +352,13 @@ def dc_block(x, R=0.995):
     return y
 
 
+def dc_block_inplace(x, R=0.995):
+    """DC_Filter::update(buf, buf, n): the aliased call (input[i-1] is read after output[i-1] overwrote it)"""
+    y = np.array(x, dtype=np.float64)
+    lib().orc_dc_block(y, y, y.size, R)
+    return y
+
+
 def lowpass1(x, epow, state):
     """state: float64[1], updated"""
     x = np.ascontiguousarray(x, dtype=np.float64)
@@ -442,6 +459,18 @@ def ref():
     R.ref_decimate.restype = _sz
     R.ref_upsample_fill_w_zeros.argtypes = [_f64, _sz, _f64, _sz, C.c_double]
     R.ref_upsample_fill_w_zeros.restype = _sz
+    R.ref_raw_upsample.argtypes = [_f64, _sz, _f64, _sz, C.c_double]
+    R.ref_raw_upsample.restype = _sz
+    R.ref_upsample.argtypes = [_f64, _sz, _f64, _sz, C.c_double]
+    R.ref_upsample.restype = _sz
+    R.ref_decimate_block.argtypes = [_f64, _sz, _sz]
+    R.ref_decimate_block.restype = _sz
+    R.ref_decimate_complex.argtypes = [_f64, _sz, _sz]
+    R.ref_decimate_complex.restype = _sz
+    R.ref_baseband_load.argtypes = [_u8, _sz, C.c_int, _f64, _f64]
+    R.ref_baseband_load.restype = _sz
+    R.ref_bpsk_demodulate2.argtypes = [C.c_void_p, _f64, _sz, _sz, _u8, _f64, _f64]
+    R.ref_bpsk_demodulate2.restype = _sz
     R.ref_bpsk_new.argtypes = [C.c_uint64, _sz]
     R.ref_bpsk_new.restype = C.c_void_p
     R.ref_bpsk_free.argtypes = [C.c_void_p]

@@ -10,6 +10,7 @@
 #include <sdrx/BPSK.h>
 #include <sdrx/FM.h>
 #include <sdrx/QPSK.h>
+#include <sdrx/Resample.h>
 #include <sdrx/filt.h>
 
 template <class T> static std::vector<T> rd(const std::string &p)
@@ -142,6 +143,61 @@ int main(int argc, char **argv)
         std::vector<double> dec;
         for (size_t i = 0; i < outb.number_of_points(); i++) dec.push_back(outb.points[i].real());
         wr(out + "qpsk_dec.f64", dec.data(), dec.size());
+    }
+    { // round 2 members: public statics, Resample.h helpers, FM::convolve, BPSK::demodulate's second overload
+        std::vector<double> st;
+        for (int i = 0; i < 2; i++) st.push_back(BPSK::LUT_REAL[i]);
+        for (int i = 0; i < 2; i++) st.push_back(BPSK::LUT_180[i]);
+        for (int i = 0; i < 129; i++) st.push_back(BPSK::RRC_COEFF[i]);
+        for (int i = 0; i < 129; i++) st.push_back(QPSK::RRC_COEFF[i]);
+        const RADIO_DATA_TYPE *luts[6] = {QPSK::LUT_REAL, QPSK::LUT_IMAG, QPSK::LUT_REAL___0, QPSK::LUT_REAL__90,
+                                          QPSK::LUT_REAL_180, QPSK::LUT_REAL_270};
+        for (const RADIO_DATA_TYPE *l : luts)
+            for (int i = 0; i < 4; i++) st.push_back(l[i]);
+        for (int i = 0; i < 64; i++) st.push_back(QPSK::DEFAULT_UNIQUE_WORD[i]);
+        st.push_back((double)sizeof(BPSK::RRC_COEFF) / sizeof(double));
+        wr(out + "statics.f64", st.data(), st.size());
+
+        std::vector<double> x = rd<double>(in + "x.f64");
+        std::vector<double> up(80 + 4, 7.25), zs(80 + 4, 7.25), rp(75 + 4, 7.25);
+        raw_upsample<RADIO_DATA_TYPE>(x.data(), 10, up.data(), 80, 8.0);
+        upsample_fill_w_zeros(x.data(), 10, zs.data(), 80, 8.0);
+        upsample(x.data(), 10, rp.data(), 75, 7.5);
+        wr(out + "rs_raw.f64", up.data(), up.size());
+        wr(out + "rs_zeros.f64", zs.data(), zs.size());
+        wr(out + "rs_ramp.f64", rp.data(), rp.size());
+        std::vector<double> d(x.begin(), x.begin() + 1001);
+        double r = (double)decimate<RADIO_DATA_TYPE>(d.data(), 1001, 4);
+        d.push_back(r);
+        wr(out + "rs_decimate.f64", d.data(), d.size());
+        BBP_Block blk(64);
+        for (size_t i = 0; i < 50; i++) { blk.points[i] = Complex(x[2 * i], x[2 * i + 1]); blk.n_points++; }
+        decimate(&blk, 3);
+        std::vector<double> bo;
+        for (size_t i = 0; i < 50; i++) { bo.push_back(blk.points[i].real()); bo.push_back(blk.points[i].imag()); }
+        bo.push_back((double)blk.n_points);
+        wr(out + "rs_decimate_block.f64", bo.data(), bo.size());
+
+        FM<RADIO_DATA_TYPE> fm(100, 100, 20, 10);
+        std::vector<double> w(x.begin() + 2000, x.begin() + 2150), acc(10, 0.5);
+        fm.convolve(x.data(), 1003, w.data(), 150, acc.data(), 10, 100);
+        wr(out + "fm_convolve.f64", acc.data(), acc.size());
+
+        BPSK b2(0x14EB, 16);
+        for (int call = 0; call < 2; call++) {
+            std::vector<double> iq = rd<double>(in + "bpsk2_iq" + std::to_string(call) + ".f64");
+            const size_t n = iq.size() / 2, ds = call == 0 ? 2 : 3;
+            Complex_Array a(Complex(0, 0), n);
+            for (size_t i = 0; i < n; i++) a[i] = Complex(iq[2 * i], iq[2 * i + 1]);
+            std::vector<uint8_t> bits(n, 0);
+            std::vector<double> pr(n, 0.0), pi(n, 0.0);
+            const size_t m = b2.demodulate(a, bits.data(), n, ds, pr.data(), pi.data());
+            wr(out + "bpsk2_bits" + std::to_string(call) + ".u8", bits.data(), m);
+            wr(out + "bpsk2_plot_re" + std::to_string(call) + ".f64", pr.data(), n);
+            wr(out + "bpsk2_plot_im" + std::to_string(call) + ".f64", pi.data(), n);
+            for (size_t i = 0; i < n; i++) { iq[2 * i] = a[i].real(); iq[2 * i + 1] = a[i].imag(); }
+            wr(out + "bpsk2_after" + std::to_string(call) + ".f64", iq.data(), iq.size());
+        }
     }
     printf("dropin_driver ok\n");
     return 0;

@@ -114,5 +114,66 @@ out["dsp_fft_in"] = z.copy()
 R.ref_fft(z.view(np.float64), 256)
 out["dsp_fft"] = z
 
+# ==== round 2 additions (their own generator: the arrays above keep their values) ====
+rng2 = np.random.default_rng(20260202)
+
+# ---- u8 I/Q ingest: Baseband_Stream::load_buffer / load_buffer_and_rotate90 (Baseband_Stream.cpp:82-148)
+allb = np.arange(256, dtype=np.uint8)
+raw = np.concatenate([np.stack([allb, allb[::-1]], axis=1), rng2.integers(0, 256, (768, 2)).astype(np.uint8)])
+out["u8_raw"] = raw
+for rot, tag in ((0, "u8"), (1, "u8_rot")):
+    re, im = np.zeros(raw.shape[0]), np.zeros(raw.shape[0])
+    assert R.ref_baseband_load(np.ascontiguousarray(raw).reshape(-1), raw.size, rot, re, im) == raw.shape[0]
+    out[f"{tag}_re"], out[f"{tag}_im"] = re, im
+
+# ---- Resample.{h,cpp}: all six helpers (inputs, outputs incl. untouched tails, return values)
+x = rng2.uniform(-3, 3, 80)
+out["rs_in"] = x
+for name, fn in (("raw_upsample", R.ref_raw_upsample), ("fill_w_zeros", R.ref_upsample_fill_w_zeros), ("upsample", R.ref_upsample)):
+    for k, (n_in, n_out, ratio) in enumerate(((10, 80, 8.0), (10, 75, 7.5), (5, 23, 4.6), (3, 2, 0.9))):
+        o = np.full(n_out + 4, 7.25)
+        fn(x.copy(), n_in, o, n_out, ratio)
+        out[f"rs_{name}_{k}"] = o
+        out[f"rs_{name}_{k}_args"] = np.array([n_in, n_out, ratio])
+z = rng2.uniform(-1, 1, 2 * 13)
+out["rs_cplx_in"] = z
+for k, (n, by) in enumerate(((13, 3), (12, 4), (13, 1), (5, 9))):
+    a = z.copy()
+    r = R.ref_decimate_complex(a, n, by)
+    out[f"rs_decimate_complex_{k}"], out[f"rs_decimate_complex_{k}_args"] = a, np.array([n, by, r])
+    a = z.copy()
+    r = R.ref_decimate_block(a, n, by)
+    out[f"rs_decimate_block_{k}"], out[f"rs_decimate_block_{k}_args"] = a, np.array([n, by, r])
+    a = z[:13].copy()
+    r = R.ref_decimate(a, n, by)
+    out[f"rs_decimate_{k}"], out[f"rs_decimate_{k}_args"] = a, np.array([n, by, r])
+
+# ---- AM modulate (AM.h:41-54) incl. a length that is not a multiple
+for k, (nb, len_mod) in enumerate(((100, 800), (37, 300), (10, 7))):
+    bits = rng2.integers(0, 2, nb).astype(np.uint8)
+    o = np.full(len_mod + 3, -5.5)
+    R.ref_am_modulate(bits.copy(), nb, o, len_mod)
+    out[f"am_mod_bits_{k}"], out[f"am_mod_out_{k}"] = bits, o
+
+# ---- BPSK::demodulate overload 2 (BPSK.cpp:178-211), two calls on one object
+h = R.ref_bpsk_new(0x14EB, 16)
+for call, ds in enumerate((2, 3)):
+    base = np.asarray(psk_test_signal(O.BPSK, 300, seed=70 + call, phase_deg=20.0, snr_db=25.0, uw_bpsk=0x14EB, uw_len=16))
+    zz = np.repeat(base.reshape(-1, 2), ds, axis=0).reshape(-1).copy()
+    n = zz.size // 2
+    out[f"bpsk2_iq{call}"] = zz.copy()
+    bits, pr, pi = np.zeros(n, dtype=np.uint8), np.zeros(n), np.zeros(n)
+    m = R.ref_bpsk_demodulate2(h, zz, n, ds, bits, pr, pi)
+    points = -(-n // ds)
+    out[f"bpsk2_args{call}"] = np.array([n, ds, m])
+    out[f"bpsk2_iq_after{call}"], out[f"bpsk2_bits{call}"] = zz, bits[:m]
+    out[f"bpsk2_plot_re{call}"], out[f"bpsk2_plot_im{call}"] = pr[:points // 4], pi[:points // 4]
+R.ref_bpsk_free(h)
+
+# ---- DC_Filter::update called in place (input == output): input[i-1] is read after it was overwritten
+y = out["dsp_in"].copy()
+R.ref_dc_block(y, y, 257, 0.995)
+out["dsp_dc_block_inplace"] = y
+
 np.savez_compressed(os.path.join(HERE, "ref_fixtures.npz"), **out)
 print("wrote", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "ref_fixtures.npz")), "bytes")

@@ -28,6 +28,9 @@ def test_cpp_dropin_classes(tmp_path, golden):
     x.tofile(ind / "x.f64")
     bits.tofile(ind / "bits.u8")
     sym.tofile(ind / "sym.u8")
+    F = np.load(os.path.join(ROOT, "tests", "golden", "ref_fixtures.npz"))  # vectors the compiled reference produced
+    for call in range(2):
+        np.ascontiguousarray(F[f"bpsk2_iq{call}"]).tofile(ind / f"bpsk2_iq{call}.f64")
     r = subprocess.run([DRIVER, str(ind), str(outd)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rd = lambda name, dt=np.float64: np.fromfile(outd / name, dtype=dt)  # noqa: E731
@@ -80,3 +83,32 @@ def test_cpp_dropin_classes(tmp_path, golden):
     amb = np.array(golden["TEST_QPSK__QPSK__Deconstructed_ModDemod__real_phaseambcorrect"])
     assert np.array_equal(rd("qpsk_amb.f64")[81:], amb[:919])
     assert np.array_equal(rd("qpsk_dec.f64"), O.psk_demodulate(O.psk_new(O.QPSK, math_mode=O.MATH_SHARED), qiq))
+
+    # ---- round 2 members
+    st = rd("statics.f64")
+    rrc = np.array((C.c_double * 129).in_dll(L, "ORC_RRC"))
+    assert list(st[:4]) == [1, -1, 1, 0]                                   # BPSK.cpp:14-15
+    assert np.array_equal(st[4:133], rrc) and np.array_equal(st[133:262], rrc)  # BPSK::RRC_COEFF, QPSK::RRC_COEFF
+    assert list(st[262:286]) == [1, -1, 1, -1, 1, 1, -1, -1, 0, 1, 2, 3, 2, 0, 3, 1, 3, 2, 1, 0, 1, 3, 0, 2]  # QPSK.cpp:14-19
+    assert list(st[286:350]) == [0] * 48 + [3, 0, 2, 1, 0, 3, 2, 1, 2, 0, 1, 2, 3, 2, 2, 3] and st[350] == 129  # QPSK.cpp:20-28
+    for name, fn, (n_in, n_out, ratio) in (("rs_raw.f64", L.orc_raw_upsample, (10, 80, 8.0)),
+                                           ("rs_zeros.f64", L.orc_upsample_fill_w_zeros, (10, 80, 8.0)),
+                                           ("rs_ramp.f64", L.orc_upsample, (10, 75, 7.5))):
+        want = np.full(n_out + 4, 7.25)
+        fn(x.copy(), n_in, want, n_out, ratio)
+        assert np.array_equal(rd(name), want), name
+    d = x[:1001].copy()
+    r = L.orc_decimate(d, 1001, 4)
+    assert np.array_equal(rd("rs_decimate.f64"), np.concatenate([d, [r]]))
+    z = x[:100].copy()
+    r = L.orc_decimate_block(z, 50, 3)
+    assert np.array_equal(rd("rs_decimate_block.f64"), np.concatenate([z, [r]]))
+    acc = np.full(10, 0.5)
+    L.orc_fm_convolve(x, 1003, np.ascontiguousarray(x[2000:2150]), 150, acc, 100)
+    assert np.array_equal(rd("fm_convolve.f64"), acc)
+    for call in range(2):  # BPSK::demodulate overload 2 against what the reference's own class produced
+        assert np.array_equal(rd(f"bpsk2_bits{call}.u8", np.uint8), F[f"bpsk2_bits{call}"])
+        k = F[f"bpsk2_plot_re{call}"].size
+        assert np.array_equal(rd(f"bpsk2_plot_re{call}.f64")[:k], F[f"bpsk2_plot_re{call}"])
+        assert np.array_equal(rd(f"bpsk2_plot_im{call}.f64")[:k], F[f"bpsk2_plot_im{call}"])
+        assert np.array_equal(rd(f"bpsk2_after{call}.f64"), F[f"bpsk2_iq_after{call}"])

@@ -506,13 +506,14 @@ def test_dsp_recurrences_bit_exact(n, cw, tune):
     for call in range(3):
         x = rng.normal(0, 30, (nchan, n)) + 2.5
         xd = _rows_dev(x)
-        # x -> y and in place give the same rows
+        # x -> y: the recurrence as written; in place: the reference's ALIASED call, which reads input[i-1] after
+        # output[i-1] overwrote it (DC_Filter.cpp:18) -- a different recurrence, pinned by a reference fixture
         y = torch.empty_like(xd)
         device.iir(device.IIR_DC_BLOCK, 0.995, xd, y)
         assert np.array_equal(y.cpu().numpy(), np.stack([O.dc_block(r, 0.995) for r in x]).reshape(nchan, n))
         z = xd.clone()
         device.iir(device.IIR_DC_BLOCK, 0.995, z)
-        assert torch.equal(z, y)
+        assert np.array_equal(z.cpu().numpy(), np.stack([O.dc_block_inplace(r, 0.995) for r in x]).reshape(nchan, n))
         z = xd.clone()
         device.iir(device.IIR_INTEGRATE, 1.0 / 48000.0, z)
         assert np.array_equal(z.cpu().numpy(), np.stack([O.integrate(r, 1.0 / 48000.0) for r in x]).reshape(nchan, n))
@@ -1221,3 +1222,151 @@ def test_psk_modulators_vs_oracle():
     host.QPSK().modulate(sym, 500, ar, ai, 4000)
     L.orc_qpsk_modulate(sym, 500, br, bi, 4000)
     assert np.array_equal(ar, br) and np.array_equal(ai, bi)
+
+
+# =============================================================================== round 2: modulators, convolve, full shapes
+
+def test_am_fm_modulator_kernels_vs_oracle():
+    """sdrx_am_modulate_dev / sdrx_fm_modulate_dev over banks of bit streams (AM.h:41-54, FM.h:44-74): every row equals
+    the oracle's modulate bit for bit; outputs the reference leaves unwritten keep their contents; repeat count 0,
+    lengths that do not divide, bit times longer than the LDS tables."""
+    rng = np.random.default_rng(5)
+    for nchan, nb, len_mod in ((3, 100, 800), (5, 37, 300), (2, 10, 7), (1, 1, 1), (4, 1000, 2999), (2, 4097, 4097 * 3 + 1)):
+        bits = rng.integers(0, 2, (nchan, nb)).astype(np.uint8)
+        out = torch.full((nchan, len_mod + 5), -5.5, dtype=torch.float64, device="cuda")
+        device.am_modulate(_rows_dev(bits), out, len_mod)
+        got = out.cpu().numpy()
+        for c in range(nchan):
+            want = O.am_modulate(bits[c], len_mod, np.full(len_mod + 5, -5.5))
+            assert np.array_equal(got[c], want), (nchan, nb, len_mod, c)
+    for spb, tx, mark, space in ((100, 100.0, 20.0, 10.0), (1, 10e6, 19000.0, 20000.0), (7, 2e6, 19000.0, 20000.0),
+                                 (2000, 10e6, 19000.0, 20000.0), (9001, 10e6, 19000.0, 20000.0)):
+        nchan, nb = 3, 70
+        bits = rng.integers(0, 2, (nchan, nb)).astype(np.uint8)
+        bits[0, :3] = [0, 1, 255]  # any non-zero byte is a mark (FM.h:62 tests == 0)
+        w1, w2 = device.fm_tables(tx, mark, space, spb, True)
+        out = torch.full((nchan, nb * spb + 3), 9.75, dtype=torch.float64, device="cuda")
+        device.fm_modulate(_rows_dev(bits), torch.tensor(w1, device="cuda"), torch.tensor(w2, device="cuda"), out)
+        got = out.cpu().numpy()
+        for c in range(nchan):
+            assert np.array_equal(got[c, : nb * spb], O.fm_modulate(tx, mark, space, bits[c], spb)), (spb, c)
+            assert np.all(got[c, nb * spb:] == 9.75)
+        d1, d2 = device.fm_tables(tx, mark, space, spb, False)  # the demodulator's tables: another operation order
+        o1, o2 = np.zeros(spb), np.zeros(spb)
+        L.orc_fm_waves(tx, mark, space, spb, o1, o2)
+        assert np.array_equal(d1, o1) and np.array_equal(d2, o2)
+
+
+def test_fm_convolve_vs_oracle_and_demodulate_identity():
+    """FM<T>::convolve (FM.h:83-108 with the repair's `ds`): sums start from the outputs' prior values; windows longer
+    and shorter than ds; fewer samples than one bit; and demodulate == compare(convolve(mark), convolve(space))."""
+    rng = np.random.default_rng(6)
+    fm = host.FM(100, 100, 20, 10)
+    for len1, len2, ds in ((1000, 100, 100), (1000, 50, 100), (1003, 150, 100), (10, 3, 1), (99, 100, 100), (4096, 16, 8), (777, 7, 50)):
+        x = rng.uniform(-100, 100, len1)
+        w = rng.uniform(-1, 1, len2)
+        n_out = len(range(ds - 1, len1, ds))
+        prior = rng.uniform(-5, 5, n_out + 2)
+        want = prior.copy()
+        L.orc_fm_convolve(x, len1, w, len2, want, ds)
+        got = prior.copy()
+        fm.convolve(x, len1, w, len2, got, n_out, ds)
+        assert np.array_equal(got, want), (len1, len2, ds)
+        dgot = torch.tensor(prior, device="cuda")
+        device.fm_convolve(torch.tensor(x, device="cuda"), torch.tensor(w, device="cuda"), dgot, ds)
+        assert np.array_equal(dgot.cpu().numpy(), want), (len1, len2, ds)
+    bits = rng.integers(0, 2, 40).astype(np.uint8)
+    mod = O.fm_modulate(100.0, 20.0, 10.0, bits, 100) + rng.normal(0, 0.05, 4000)
+    w1, w2 = device.fm_tables(100.0, 20.0, 10.0, 100, False)
+    op1, op2 = np.zeros(40), np.zeros(40)
+    fm.convolve(mod, 4000, w1, 100, op1, 40, 100)
+    fm.convolve(mod, 4000, w2, 100, op2, 40, 100)
+    out = np.zeros(40, dtype=np.uint8)
+    assert fm.demodulate(mod, mod, out, 4000, 100) == 40
+    assert np.array_equal(out, (op1 > op2).astype(np.uint8)) and np.array_equal(out, bits)
+
+
+def test_u8_input_with_fast_mode_2_runs_as_mode_1():
+    """sdrx.h: shapes the MFMA kernel lacks run as mode 1.  Raw-byte input is one of them (the MFMA kernel reads fp64
+    rails): FirChain.fir(uint8, fast_fma=2) must equal the fused VALU chain on (byte - bias), not fault."""
+    err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
+    rng = np.random.default_rng(8)
+    raw = rng.integers(0, 256, (2, 5003, 2)).astype(np.uint8)
+    ch = device.FirChain(taps, nchan=2, decim=1)
+    o0 = torch.zeros(2, 5003, dtype=torch.float64, device="cuda")
+    o1 = torch.zeros_like(o0)
+    ch.fir(torch.tensor(raw, device="cuda"), o0, o1, fast_fma=2)
+    assert b"fir_tile_kernel" in _lib.lib().sdrx_last_kernel() and b"fma" in _lib.lib().sdrx_last_kernel()
+    for c in range(2):
+        re, im = O.u8_to_iq(raw[c])
+        assert np.array_equal(o0[c].cpu().numpy(), O.Fir(O.LPF, 64, 2.0e6, 1.0e5).execute_fma(re))
+        assert np.array_equal(o1[c].cpu().numpy(), O.Fir(O.LPF, 64, 2.0e6, 1.0e5).execute_fma(im))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_config5_full_shape_bank(mode):
+    """BASELINE config 5 at the shape bench.py times (1024 channels x 2^18 real samples, T = 1024): 8 distinct rows
+    repeated 128 times: every copy equals the first; the first 3000 outputs and the last 500 of the 8 distinct rows equal
+    the oracle (mode 0: the reference's two-rounding chain; modes 1 and 2: the fused chain, bit for bit)."""
+    T, nchan, n, distinct = 1024, 1024, 1 << 18, 8
+    err, taps = O.fir_design(O.LPF, T, 2.0e6, 1.0e5, max_taps=4096)
+    assert err == 0
+    g = torch.Generator(device="cuda").manual_seed(55)
+    base = torch.randint(-127, 128, (distinct, n), generator=g, device="cuda").to(torch.float64)
+    x = base.repeat(nchan // distinct, 1).contiguous()
+    out = torch.zeros(nchan, n, dtype=torch.float64, device="cuda")
+    device.FirChain(taps, nchan, 1).fir(x, out, fast_fma=mode)
+    o = out.view(nchan // distinct, distinct, -1)
+    assert torch.equal(o, o[0:1].expand_as(o))
+    hb = base.cpu().numpy()
+    for c in range(distinct):
+        f = O.Fir(O.LPF, T, 2.0e6, 1.0e5, max_taps=4096)
+        head = f.execute_fma(hb[c, :3000]) if mode else f.execute(hb[c, :3000], fast=True)
+        assert np.array_equal(out[c, :3000].cpu().numpy(), head), (mode, c)
+        f2 = O.Fir(O.LPF, T, 2.0e6, 1.0e5, max_taps=4096)
+        seg = hb[c, n - 500 - (T - 1):]
+        tail = f2.execute_fma(seg) if mode else f2.execute(seg, fast=True)
+        assert np.array_equal(out[c, n - 500:].cpu().numpy(), tail[T - 1:]), (mode, c)
+
+
+def test_config3_full_shape_bank_bpsk():
+    """test_config3_full_shape_bank for BPSK (2^14 channels x 2^12 samples, two blocks, 64-bit unique word as the
+    receiver constructs it, rtlsdr_receiver.cpp:230)."""
+    nchan, n, distinct, uw = 1 << 14, 1 << 12, 64, 0xDEADBEEF600DF00D
+    bank = device.PskBank(_lib.BPSK, nchan, n, unique_word=uw, uw_len=64)
+    sts = [O.psk_new(O.BPSK, uw, 64, O.MATH_SHARED) for _ in range(distinct)]
+    for blk in range(2):
+        sig = np.stack([psk_test_signal(O.BPSK, n // 8, seed=8000 + 100 * blk + c, phase_deg=(31 * c) % 360, snr_db=16.0,
+                                        timing_offset=c % 8, uw_bpsk=uw).reshape(n, 2) for c in range(distinct)])
+        iq = torch.tensor(sig, device="cuda").repeat(nchan // distinct, 1, 1).contiguous()
+        out = torch.zeros(nchan, bank.n_dec, dtype=torch.uint8, device="cuda")
+        bank.demod(iq, out)
+        torch.cuda.synchronize()
+        o = out.view(nchan // distinct, distinct, -1)
+        assert torch.equal(o, o[0:1].expand_as(o))
+        stt = bank.states.view(nchan // distinct, distinct, -1)
+        assert torch.equal(stt, stt[0:1].expand_as(stt))
+        got, hs = out[:distinct].cpu().numpy(), bank.states[:distinct].cpu().numpy()
+        for c in range(distinct):
+            want = O.psk_demodulate(sts[c], np.ascontiguousarray(sig[c].reshape(-1)))
+            assert np.array_equal(got[c][: want.size].astype(np.float64), want), (blk, c)
+            assert np.array_equal(hs[c][: 8 * 24].view(np.float64), sts[c].loop_state()), (blk, c)
+            assert int(hs[c][8 * 24: 8 * 24 + 4].view(np.int32)[0]) == sts[c].cc[0]
+
+
+def test_config1_at_its_stated_size():
+    """BASELINE config 1 as stated: ONE 2^20-sample I/Q buffer, Filter(LPF,64,2e6,1e5) on I and Q, AM threshold with
+    ds = 1 and ds = 8, through sdrx_fir_am_dev; every bit equals the oracle's chain (OOK carrier of amplitude 100 on
+    random bits + noise, so both bit values and samples near the threshold occur)."""
+    err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
+    n = 1 << 20
+    re, im, _ = ook_iq(n, seed=1, ds=8)
+    x = torch.tensor(np.stack([re, im], axis=-1)[None], device="cuda")
+    for ds in (1, 8):
+        ch = device.FirChain(taps, 1, ds)
+        bits = torch.zeros(1, ch.n_out(n), dtype=torch.uint8, device="cuda")
+        ch.fir_am(x, bits)
+        want = np.zeros(n + 1, dtype=np.uint8)
+        m = L.orc_chain_fir_am(taps, 64, np.zeros(63), np.zeros(63), re, im, n, ds, want)
+        assert m == bits.shape[1] and np.array_equal(bits[0].cpu().numpy(), want[:m]), ds
+        assert 0.2 < want[:m].mean() < 0.8

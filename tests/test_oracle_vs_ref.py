@@ -157,6 +157,70 @@ def test_resample_helpers_match_reference():
         assert np.array_equal(a, b)
 
 
+def test_every_resample_function_matches_reference():
+    """Resample.h:12-54 / Resample.cpp:10-70, all six: upsample (ramp), raw_upsample, upsample_fill_w_zeros,
+    decimate<T>, decimate(BBP_Block*) (drops the first point, n_points = kept + 1), decimateComplexArray (tail quirk)."""
+    R = O.ref()
+    rng = np.random.default_rng(10)
+    for n_in, n_out, ratio in ((10, 80, 8.0), (10, 75, 7.5), (7, 7, 1.0), (5, 23, 4.6), (3, 2, 0.9), (6, 13, 2.2)):
+        x = rng.uniform(-3, 3, n_in + 64)  # upsample() ignores in_length: give it room to read on
+        for fn_r, fn_o in ((R.ref_raw_upsample, L.orc_raw_upsample), (R.ref_upsample_fill_w_zeros, L.orc_upsample_fill_w_zeros),
+                           (R.ref_upsample, L.orc_upsample)):
+            a, b = np.full(n_out + 4, 7.25), np.full(n_out + 4, 7.25)  # untouched outputs must stay untouched
+            assert fn_r(x.copy(), n_in, a, n_out, ratio) == fn_o(x.copy(), n_in, b, n_out, ratio)
+            assert np.array_equal(a, b), (fn_o, n_in, n_out, ratio)
+    for n, by in ((1000, 2), (1001, 4), (17, 5), (8, 8), (3, 10), (1, 1), (12, 3), (13, 3)):
+        z = rng.uniform(-1, 1, 2 * n)
+        a, b = z.copy(), z.copy()
+        assert R.ref_decimate_complex(a, n, by) == L.orc_decimate_complex(b, n, by)
+        assert np.array_equal(a, b), ("decimateComplexArray", n, by)
+        a, b = z.copy(), z.copy()
+        assert R.ref_decimate_block(a, n, by) == L.orc_decimate_block(b, n, by)
+        assert np.array_equal(a, b), ("decimate(BBP_Block*)", n, by)
+
+
+@pytest.mark.parametrize("rotate90", [False, True])
+def test_u8_ingest_matches_baseband_stream(rotate90):
+    """orc_u8_to_iq / orc_u8_rotate_90 against Baseband_Stream::load_buffer / load_buffer_and_rotate90
+    (Baseband_Stream.cpp:82-148) driven through the stream's own thread and post callback: `char` bytes (signed on
+    x86), bias 127.4, rotate_90 on groups of four samples.  Every byte value on both rails, plus random blocks."""
+    R = O.ref()
+    rng = np.random.default_rng(11 + int(rotate90))
+    allb = np.arange(256, dtype=np.uint8)
+    raws = [np.stack([allb, allb[::-1]], axis=1), np.stack([np.roll(allb, 77), allb], axis=1),
+            rng.integers(0, 256, (4096, 2)).astype(np.uint8)]
+    for raw in raws:
+        n = raw.shape[0]
+        re, im = np.zeros(n), np.zeros(n)
+        assert R.ref_baseband_load(np.ascontiguousarray(raw).reshape(-1), 2 * n, int(rotate90), re, im) == n
+        ore, oim = O.u8_to_iq(raw, 127.4, signed_char=True, rotate90=rotate90)
+        assert np.array_equal(re, ore) and np.array_equal(im, oim)
+
+
+def test_bpsk_demodulate_overload_2_matches_reference():
+    """BPSK::demodulate(Complex_Array&, uint8_t*, n, downsample, plot_re, plot_im) (BPSK.cpp:178-211) = decimateComplexArray
+    + the stages, post-timing samples to the plot buffers, bits = real > 0.5.  Two calls on one object (state carried)."""
+    R = O.ref()
+    h = R.ref_bpsk_new(0x14EB, 16)
+    st = O.psk_new(O.BPSK, 0x14EB, 16)
+    for call, ds in enumerate((2, 3)):
+        base = np.asarray(psk_test_signal(O.BPSK, 300, seed=70 + call, phase_deg=20.0, snr_db=25.0, uw_bpsk=0x14EB, uw_len=16))
+        z = np.repeat(base.reshape(-1, 2), ds, axis=0).reshape(-1).copy()  # the transmitter's raw_upsample
+        n = z.size // 2
+        a = z.copy()
+        bits, pr, pi = np.zeros(n, dtype=np.uint8), np.zeros(n), np.zeros(n)
+        m = R.ref_bpsk_demodulate2(h, a, n, ds, bits, pr, pi)
+        b = z.copy()
+        points = L.orc_decimate_complex(b, n, ds)
+        assert np.array_equal(a, b)  # the caller's array after decimateComplexArray
+        out, tr, ti = np.zeros(n), np.zeros(n), np.zeros(n)
+        m2 = L.orc_psk_demodulate(C.byref(st), b[:2 * points].copy(), points, out, tr.ctypes.data, ti.ctypes.data)
+        assert m == m2
+        assert np.array_equal(bits[:m], (out[:m] > 0.5).astype(np.uint8))
+        assert np.array_equal(pr[:points // 4], tr[:points // 4]) and np.array_equal(pi[:points // 4], ti[:points // 4])
+    R.ref_bpsk_free(h)
+
+
 # ---------------------------------------------------------------- crc8 / PacketFramer / RingBuffer
 
 def test_crc8_and_frame_vs_reference():

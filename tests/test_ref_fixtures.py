@@ -69,6 +69,105 @@ def test_dsp_primitive_fixtures():
     assert np.max(np.abs(O.fft(z, O.MATH_SHARED) - F["dsp_fft"])) <= 1e-12 * 8 * np.abs(F["dsp_fft"]).max()
 
 
+def test_u8_ingest_fixture():
+    """orc_u8_* against what Baseband_Stream::load_buffer / load_buffer_and_rotate90 produced (every byte value on both
+    rails): the `char` reading, the 127.4 bias and rotate_90's byte order are the reference's, not a reading of them."""
+    raw = np.ascontiguousarray(F["u8_raw"])
+    for rot, tag in ((False, "u8"), (True, "u8_rot")):
+        re, im = O.u8_to_iq(raw, 127.4, signed_char=True, rotate90=rot)
+        assert np.array_equal(re, F[f"{tag}_re"]) and np.array_equal(im, F[f"{tag}_im"])
+
+
+def test_resample_fixtures():
+    x = np.ascontiguousarray(F["rs_in"])
+    for name, fn in (("raw_upsample", L.orc_raw_upsample), ("fill_w_zeros", L.orc_upsample_fill_w_zeros), ("upsample", L.orc_upsample)):
+        for k in range(4):
+            n_in, n_out, ratio = F[f"rs_{name}_{k}_args"]
+            o = np.full(int(n_out) + 4, 7.25)
+            fn(x.copy(), int(n_in), o, int(n_out), float(ratio))
+            assert np.array_equal(o, F[f"rs_{name}_{k}"]), (name, k)
+    z = np.ascontiguousarray(F["rs_cplx_in"])
+    for k in range(4):
+        for name, fn, src in (("decimate_complex", L.orc_decimate_complex, z), ("decimate_block", L.orc_decimate_block, z),
+                              ("decimate", L.orc_decimate, z[:13])):
+            n, by, r = (int(v) for v in F[f"rs_{name}_{k}_args"])
+            a = src.copy()
+            assert fn(a, n, by) == r, (name, k)
+            assert np.array_equal(a, F[f"rs_{name}_{k}"]), (name, k)
+
+
+def test_am_modulate_and_bpsk_overload_2_fixtures():
+    for k in range(3):
+        bits = np.ascontiguousarray(F[f"am_mod_bits_{k}"])
+        want = F[f"am_mod_out_{k}"]
+        o = np.full(want.size, -5.5)
+        L.orc_am_modulate(bits, bits.size, o, want.size - 3)
+        assert np.array_equal(o, want), k
+    import ctypes as C
+    st = O.psk_new(O.BPSK, 0x14EB, 16)
+    for call in range(2):
+        n, ds, m = (int(v) for v in F[f"bpsk2_args{call}"])
+        z = np.ascontiguousarray(F[f"bpsk2_iq{call}"]).copy()
+        points = L.orc_decimate_complex(z, n, ds)
+        assert np.array_equal(z, F[f"bpsk2_iq_after{call}"])
+        out, tr, ti = np.zeros(n), np.zeros(n), np.zeros(n)
+        assert L.orc_psk_demodulate(C.byref(st), z[:2 * points].copy(), points, out, tr.ctypes.data, ti.ctypes.data) == m
+        assert np.array_equal((out[:m] > 0.5).astype(np.uint8), F[f"bpsk2_bits{call}"])
+        assert np.array_equal(tr[:points // 4], F[f"bpsk2_plot_re{call}"]) and np.array_equal(ti[:points // 4], F[f"bpsk2_plot_im{call}"])
+    assert np.array_equal(O.dc_block_inplace(F["dsp_in"], 0.995), F["dsp_dc_block_inplace"])
+
+
+@pytest.mark.gpu
+def test_device_psk_u8_and_new_members_against_reference_fixtures():
+    """The HIP path against the reference's own outputs directly, second batch: whole BPSK / QPSK blocks (decisions,
+    confidence counters, the timing loop's state bit for bit; the carrier loop's three state doubles to 1e-9 -- the
+    device's sincos is include/sdrx_math.h, the reference's is libm), the raw-byte conversion of the FIR kernels, AM
+    modulate, BPSK::demodulate's second overload, DC_Filter called in place."""
+    torch = pytest.importorskip("torch")
+    from sdr_amd import _lib, device, host
+    device.init(0)
+    for tag, obj in (("bpsk", host.BPSK(0xDEADBEEF600DF00D, 64)), ("qpsk", host.QPSK())):
+        for blk in range(2):
+            got = obj.demodulate(np.ascontiguousarray(F[f"{tag}_iq{blk}"]))
+            assert np.array_equal(got, F[f"{tag}_dec{blk}"]), (tag, blk)
+            ls, want = obj.loop_state(), F[f"{tag}_state{blk}"]
+            assert np.array_equal(ls[:21], want[:21]), (tag, blk, "timing-loop state")
+            assert np.allclose(ls[21:], want[21:], rtol=0, atol=1e-9), (tag, blk, "carrier-loop state")
+            ncc = 1 if tag == "bpsk" else 4
+            assert list(obj.state().cc)[:ncc] == list(F[f"{tag}_cc{blk}"][:ncc])
+    # raw bytes through the FIR kernels' load path: a one-tap filter h = {1} returns the converted samples themselves
+    raw = torch.tensor(np.ascontiguousarray(F["u8_raw"])[None], device="cuda")
+    n = raw.shape[1]
+    for rot, tag in ((False, "u8"), (True, "u8_rot")):
+        for D in (1, 10):  # tile kernel, systolic kernel (its staging converts too)
+            taps = np.array([1.0]) if D == 1 else np.concatenate([[1.0], np.zeros(63)])
+            ch = device.FirChain(taps, nchan=1, decim=D)
+            ch.set_u8_conversion(127.4, signed_char=True, rotate90=rot)
+            o0 = torch.zeros(1, ch.n_out(n), dtype=torch.float64, device="cuda")
+            o1 = torch.zeros_like(o0)
+            ch.fir(raw, o0, o1)
+            assert np.array_equal(o0[0].cpu().numpy(), F[f"{tag}_re"][::D]) and np.array_equal(o1[0].cpu().numpy(), F[f"{tag}_im"][::D])
+    for k in range(3):
+        bits = np.ascontiguousarray(F[f"am_mod_bits_{k}"])
+        want = F[f"am_mod_out_{k}"]
+        o = np.full(want.size, -5.5)
+        host.AM().modulate(bits, bits.size, o, None, want.size - 3)
+        assert np.array_equal(o, want), k
+    b = host.BPSK(0x14EB, 16)
+    for call in range(2):
+        n, ds, m = (int(v) for v in F[f"bpsk2_args{call}"])
+        z = np.ascontiguousarray(F[f"bpsk2_iq{call}"]).copy()
+        bits, pr, pi = np.zeros(n, dtype=np.uint8), np.zeros(n), np.zeros(n)
+        assert b.demodulate_array(z, bits, n, ds, pr, pi) == m
+        assert np.array_equal(z, F[f"bpsk2_iq_after{call}"])
+        assert np.array_equal(bits[:m], F[f"bpsk2_bits{call}"])
+        k = F[f"bpsk2_plot_re{call}"].size
+        assert np.array_equal(pr[:k], F[f"bpsk2_plot_re{call}"]) and np.array_equal(pi[:k], F[f"bpsk2_plot_im{call}"])
+    x = torch.tensor(np.ascontiguousarray(F["dsp_in"])[None], device="cuda")
+    device.iir(device.IIR_DC_BLOCK, [0.995], x)  # in place
+    assert np.array_equal(x[0].cpu().numpy(), F["dsp_dc_block_inplace"])
+
+
 @pytest.mark.gpu
 def test_device_against_reference_fixtures():
     """The HIP path against the reference's own outputs directly (no oracle in between): Filter through the drop-in
