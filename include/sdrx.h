@@ -158,6 +158,13 @@ int sdrx_rtlfm_full_dev(const sdrx_rtlfm_params *params, const uint8_t *iq_u8, s
                         const int32_t *state_in, int32_t *state_out, int32_t *post_state, int64_t *work, int16_t *pcm,
                         size_t out_pitch, void *stream);
 
+/* low_pass_real (rtl_fm.c:341-361), full_demod's last stage when rate_out2 > 0 (:788-789): in place on the pcm rows
+ * sdrx_rtlfm_full_dev left (row length = post_state[4c+3], which receives the new result_len), a boxcar over the
+ * rate change rate_out -> rate_out2: result[k] = (int16)(window sum / (rate_out / rate_out2)).  lpr_state, 2 x int32
+ * per channel, read and written: now_lpr, prev_lpr_index (zeros for a new demod_state).  0 < rate_out2 <= rate_out. */
+int sdrx_rtlfm_low_pass_real_dev(int16_t *pcm, size_t nchan, size_t out_pitch, int rate_out, int rate_out2,
+                                 int32_t *post_state, int32_t *lpr_state, void *stream);
+
 /* The bit-domain back end of the receive path: what RtlSdr_Receiver::deserializeData (rtlsdr_receiver.cpp:2197-2230)
  * does with PacketFramer<T>::deserialize (network/PacketFramer.h:424-513), RingBuffer<T> and crc8 (crc/crc8.cpp), on
  * `nchan` independent bit streams (one byte per bit, as the demodulators write them).  The n bits of a call are the ring
@@ -297,6 +304,10 @@ void sdrx_fir_get_taps(const sdrx_fir_t *f, double *taps); /* filt.cpp:156-166 *
 void sdrx_fir_reset(sdrx_fir_t *f);                       /* Filter::init, filt.cpp:236-246 */
 int sdrx_fir_execute(sdrx_fir_t *f, double *buf, size_t n); /* Filter::execute, in place, state carried */
 double sdrx_fir_do_sample(sdrx_fir_t *f, double x);       /* Filter::do_sample (one-sample launch) */
+/* Filter::execute on nchan Filter objects at once (e.g. the I and Q rails of every radio): bufs[c] (n doubles each) is
+ * filtered in place by h[c], every object's shift register carried as in sdrx_fir_execute.  All buffers go through one
+ * pinned block and objects of the same design (identical taps) share ONE launch.  An object may appear only once. */
+int sdrx_fir_execute_batch(sdrx_fir_t *const *h, double *const *bufs, size_t n, size_t nchan);
 
 size_t sdrx_am_demodulate(const double *re, const double *im, uint8_t *out, size_t n, size_t ds); /* AM.h:63-77 */
 void sdrx_am_modulate(const uint8_t *bits, size_t len, double *out_real, size_t len_mod);         /* AM.h:41-54 */

@@ -420,6 +420,29 @@ size_t orc_rtlfm_full(const uint8_t *iq_u8, size_t n, int downsample, int rotate
     return (size_t)result_len;
 }
 
+/* low_pass_real, rtl_fm.c:341-361: result[] in place, lpr = {now_lpr, prev_lpr_index}; returns the new result_len.
+ * PARITY UNPINNED like the rest of the rtl_fm chain. */
+int orc_rtlfm_low_pass_real(int16_t *result, int result_len, int rate_out, int rate_out2, int32_t *lpr)
+{
+    int i = 0, i2 = 0;
+    int fast = rate_out;
+    int slow = rate_out2;
+    int now_lpr = lpr[0], prev_lpr_index = lpr[1];
+    while (i < result_len) {
+        now_lpr += result[i];
+        i++;
+        prev_lpr_index += slow;
+        if (prev_lpr_index < fast) continue;
+        result[i2] = (int16_t)(now_lpr / (fast / slow));
+        prev_lpr_index -= fast;
+        now_lpr = 0;
+        i2 += 1;
+    }
+    lpr[0] = now_lpr;
+    lpr[1] = prev_lpr_index;
+    return i2;
+}
+
 /* ---------------------------------------------------------------- Resample */
 
 size_t orc_decimate(double *block, size_t length, size_t by)

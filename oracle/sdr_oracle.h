@@ -87,6 +87,7 @@ size_t orc_rtlfm_chain(const uint8_t *iq_u8, size_t n, int downsample, int rotat
 /* ---- Resample.{h,cpp} ---- */
 size_t orc_rtlfm_full(const uint8_t *iq_u8, size_t n, int downsample, int rotate90, int squelch_level, int post_downsample,
                       int deemph_a, int dc_block, int32_t *st, int32_t *post, int16_t *pcm, size_t cap, int math_mode);
+int orc_rtlfm_low_pass_real(int16_t *result, int result_len, int rate_out, int rate_out2, int32_t *lpr); /* rtl_fm.c:341-361 */
 size_t orc_decimate(double *block, size_t length, size_t by);                                  /* Resample.h:33-52 */
 size_t orc_upsample_fill_w_zeros(const double *in, size_t in_len, double *out, size_t out_len, double ratio); /* Resample.cpp:24-36 */
 size_t orc_raw_upsample(const double *in, size_t in_len, double *out, size_t out_len, double ratio);          /* Resample.h:15-27 */

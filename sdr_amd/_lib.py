@@ -72,6 +72,7 @@ SIGNATURES = {
     "sdrx_fm_demod_dev": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp]),
     "sdrx_rtlfm_dev": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, C.c_int, _vp, _vp, _vp, _sz, _vp]),
     "sdrx_rtlfm_full_dev": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sdrx_rtlfm_low_pass_real_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, C.c_int, _vp, _vp, _vp]),
     "sdrx_deframe_dev": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _sz, _vp, _vp]),
     "sdrx_iir_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "sdrx_lowpass1_coef": (C.c_double, [C.c_double, C.c_double]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "sdrx_fir_reset": (None, [_vp]),
     "sdrx_fir_execute": (C.c_int, [_vp, _vp, _sz]),
     "sdrx_fir_do_sample": (C.c_double, [_vp, C.c_double]),
+    "sdrx_fir_execute_batch": (C.c_int, [_vp, _vp, _sz, _sz]),
     "sdrx_am_demodulate": (_sz, [_vp, _vp, _vp, _sz, _sz]),
     "sdrx_am_modulate": (None, [_vp, _sz, _vp, _sz]),
     "sdrx_fm_demodulate": (_sz, [C.c_double, C.c_double, C.c_double, _vp, _vp, _sz, _sz]),

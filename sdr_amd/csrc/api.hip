@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <vector>
 #include <vector>
@@ -230,6 +231,12 @@ extern "C" int sdrx_rtlfm_full_dev(const sdrx_rtlfm_params *params, const uint8_
 {
     return launch_rtlfm_full(params, iq_u8, n, nchan, in_pitch, state_in, state_out, post_state, work, pcm, out_pitch,
                              (hipStream_t)stream);
+}
+
+extern "C" int sdrx_rtlfm_low_pass_real_dev(int16_t *pcm, size_t nchan, size_t out_pitch, int rate_out, int rate_out2,
+                                            int32_t *post_state, int32_t *lpr_state, void *stream)
+{
+    return launch_rtlfm_low_pass_real(pcm, nchan, out_pitch, rate_out, rate_out2, post_state, lpr_state, (hipStream_t)stream);
 }
 
 extern "C" int sdrx_deframe_dev(const uint8_t *bits, size_t n, size_t nchan, size_t in_pitch, int crc_enable,
@@ -648,6 +655,101 @@ extern "C" int sdrx_fir_execute(sdrx_fir_t *f, double *buf, size_t n)
     SDRX_HIP(hipMemcpyAsync(f->out.host, f->out.dev, bytes, hipMemcpyDeviceToHost, f->stream));
     SDRX_HIP(hipStreamSynchronize(f->stream));
     staged_copy(buf, f->out.host, bytes);
+    return SDRX_OK;
+}
+
+// ---- Filter::execute on many Filter objects at once: one staging block, one upload, ONE launch per filter design
+// (the objects keep their own shift registers: rows are gathered into a batch state before the launch and scattered
+// back after it by a copy kernel driven by a pointer table)
+__global__ void __launch_bounds__(128) fir_state_rows_kernel(double *__restrict__ batch, double *const *__restrict__ table,
+                                                             size_t row, size_t pitch, int scatter)
+{
+    double *obj = table[blockIdx.x];
+    double *b = batch + (size_t)blockIdx.x * pitch;
+    for (size_t k = threadIdx.x; k < row; k += blockDim.x) {
+        if (scatter) obj[k] = b[k];
+        else b[k] = obj[k];
+    }
+}
+
+extern "C" int sdrx_fir_execute_batch(sdrx_fir_t *const *h, double *const *bufs, size_t n, size_t nchan)
+{
+    if ((!h || !bufs) && nchan) return SDRX_EINVAL;
+    for (size_t c = 0; c < nchan; c++)
+        if (!h[c] || (!bufs[c] && n)) {
+            set_error("sdrx_fir_execute_batch: null filter or buffer at channel %zu", c);
+            return SDRX_EINVAL;
+        }
+    if (n == 0 || nchan == 0) return SDRX_OK;
+    std::vector<char> done(nchan, 0);
+    for (size_t c = 0; c < nchan; c++) { // an object with its error flag set returns zeros (filt.cpp:254)
+        if (h[c]->err != 0) {
+            for (size_t i = 0; i < n; i++) bufs[c][i] = 0.0;
+            done[c] = 1;
+        }
+        for (size_t d = 0; d < c; d++)
+            if (h[d] == h[c]) {
+                set_error("sdrx_fir_execute_batch: filter object listed twice (channels %zu and %zu)", d, c);
+                return SDRX_EINVAL;
+            }
+    }
+    std::vector<size_t> grp;
+    for (size_t lead = 0; lead < nchan; lead++) {
+        if (done[lead]) continue;
+        sdrx_fir *f0 = h[lead];
+        grp.clear();
+        for (size_t c = lead; c < nchan; c++) // every object of the same design (same taps, bit for bit) goes in this launch
+            if (!done[c] && h[c]->T == f0->T && memcmp(h[c]->taps.data(), f0->taps.data(), (size_t)f0->T * sizeof(double)) == 0) {
+                grp.push_back(c);
+                done[c] = 1;
+            }
+        const size_t g = grp.size(), pitch = sdrx_fir_state_doubles(f0->T);
+        const size_t samp_bytes = align256(g * n * sizeof(double)), tab_bytes = align256(2 * g * sizeof(double *)),
+                     st_bytes = align256(g * pitch * sizeof(double));
+        int rc = f0->in.ensure(samp_bytes + tab_bytes + 2 * st_bytes);
+        if (rc) return rc;
+        rc = f0->out.ensure(samp_bytes);
+        if (rc) return rc;
+        char *hin = (char *)f0->in.host, *din = (char *)f0->in.dev;
+        double **tab = (double **)(hin + samp_bytes); // [0, g): state_in rows of the objects; [g, 2g): their state_out rows
+        for (size_t k = 0; k < g; k++) {
+            sdrx_fir *f = h[grp[k]];
+            staged_copy(hin + k * n * sizeof(double), bufs[grp[k]], n * sizeof(double));
+            tab[k] = f->d_state[f->cur];
+            tab[g + k] = f->d_state[f->cur ^ 1];
+        }
+        hipStream_t st = f0->stream;
+        SDRX_HIP(hipMemcpyAsync(din, hin, samp_bytes + tab_bytes, hipMemcpyHostToDevice, st));
+        double **dtab = (double **)(din + samp_bytes);
+        double *bst_in = (double *)(din + samp_bytes + tab_bytes), *bst_out = (double *)(din + samp_bytes + tab_bytes + st_bytes);
+        hipLaunchKernelGGL(fir_state_rows_kernel, dim3((unsigned)g), dim3(128), 0, st, bst_in, dtab, pitch, pitch, 0);
+        sdrx_fir_job j;
+        memset(&j, 0, sizeof(j));
+        j.layout = SDRX_REAL;
+        j.in0 = din;
+        j.n = n;
+        j.nchan = g;
+        j.in_pitch = n;
+        j.taps = f0->d_taps;
+        j.num_taps = f0->T;
+        j.decim = 1;
+        j.state_in = bst_in;
+        j.state_out = bst_out;
+        j.state_pitch = pitch;
+        j.out0 = f0->out.dev;
+        j.out_pitch = n;
+        j.stream = st;
+        rc = launch_fir(&j, EPI_STORE);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fir_state_rows_kernel, dim3((unsigned)g), dim3(128), 0, st, bst_out, dtab + g, pitch, pitch, 1);
+        SDRX_HIP(hipGetLastError());
+        SDRX_HIP(hipMemcpyAsync(f0->out.host, f0->out.dev, g * n * sizeof(double), hipMemcpyDeviceToHost, st));
+        SDRX_HIP(hipStreamSynchronize(st));
+        for (size_t k = 0; k < g; k++) {
+            h[grp[k]]->cur ^= 1;
+            staged_copy(bufs[grp[k]], (char *)f0->out.host + k * n * sizeof(double), n * sizeof(double));
+        }
+    }
     return SDRX_OK;
 }
 
@@ -1262,6 +1364,9 @@ struct Radio {
 std::vector<Radio> g_am, g_fm;
 double g_fm_mark = 19000, g_fm_space = 20000;
 size_t g_fm_rate = 0, g_fm_spb = 0;
+// The receiver runs one demodulating thread per RADIO_ID (rtlsdr_receiver.cpp:191-194): demodulations hold this lock
+// shared while they use the mark / space tables, whoever rebuilds the tables (a new samples-per-bit) holds it alone.
+std::shared_mutex g_fm_mu;
 
 bool radio_alloc(Radio &r, size_t max_points)
 {
@@ -1373,6 +1478,7 @@ extern "C" void fm_gpu_set_samples_per_bit(size_t samples_per_bit, size_t rx_sam
 {
     // The receiver declares and calls this with ONE argument (rtlsdr_receiver.cpp:103,1720), so the
     // second may be garbage: anything that is not a plausible rate falls back to the init-time rate.
+    std::unique_lock<std::shared_mutex> lk(g_fm_mu);
     size_t rate = (rx_sample_rate == 0 || rx_sample_rate > 1000000000000ULL) ? g_fm_rate : rx_sample_rate;
     if (!fm_upload_waves(samples_per_bit, rate)) printf("[HIP][fm_gpu_set_samples_per_bit] Error!\n");
 }
@@ -1386,9 +1492,17 @@ extern "C" double fm_gpu_demodulation(int RADIO_ID, double *real, double *imag, 
         printf("[HIP][fm_gpu_demodulation] Error!\n");
         return 0.0;
     }
-    if (ds != g_fm_spb && !fm_upload_waves(ds, g_fm_rate)) { // kernel is launched with WaveSize = ds (fm.cu:149)
-        printf("[HIP][fm_gpu_demodulation] Error!\n");
-        return 0.0;
+    std::shared_lock<std::shared_mutex> rd(g_fm_mu);
+    while (ds != g_fm_spb) { // kernel is launched with WaveSize = ds (fm.cu:149): rebuild the tables, alone
+        rd.unlock();
+        {
+            std::unique_lock<std::shared_mutex> wr(g_fm_mu);
+            if (ds != g_fm_spb && !fm_upload_waves(ds, g_fm_rate)) {
+                printf("[HIP][fm_gpu_demodulation] Error!\n");
+                return 0.0;
+            }
+        }
+        rd.lock();
     }
     Radio &r = g_fm[RADIO_ID];
     const size_t bytes = number_of_points * sizeof(double);

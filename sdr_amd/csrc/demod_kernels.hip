@@ -630,6 +630,72 @@ __global__ void __launch_bounds__(256) rtlfm_post_kernel(int16_t *__restrict__ p
     if (tid == 0) ps[3] = len;
 }
 
+// low_pass_real (rtl_fm.c:341-361), the last stage of full_demod when rate_out2 > 0 (:788-789): a boxcar over a
+// rational rate change.  Sample i is added to now_lpr, prev_lpr_index += slow, and once it reaches fast the window's
+// sum / (fast / slow) is emitted.  Which samples close a window depends only on (prev_lpr_index, slow, fast):
+// output k closes at i_k = ceil(((k+1) fast - prev0) / slow) - 1, so windows are independent integer sums: one lane
+// per output.  In place: output k lands at index k <= i_k, below everything later chunks read, so the row is walked in
+// chunks (loads, barrier, stores).  One workgroup per channel.  lpr[2 chan] = {now_lpr, prev_lpr_index}, carried.
+__global__ void __launch_bounds__(256) rtlfm_low_pass_real_kernel(int16_t *__restrict__ pcm_all, size_t out_pitch, int fast,
+                                                                   int slow, int32_t *__restrict__ post_state,
+                                                                   int32_t *__restrict__ lpr_all)
+{
+    __shared__ long long red[4];
+    const size_t chan = blockIdx.x;
+    const unsigned tid = threadIdx.x;
+    int16_t *res = pcm_all + chan * out_pitch;
+    int32_t *ps = post_state + 4 * chan, *lpr = lpr_all + 2 * chan;
+    const long long len = ps[3], prev0 = lpr[1], F = fast, S = slow;
+    const int now0 = lpr[0], div = fast / slow;
+    const long long K = len > 0 ? (prev0 + len * S) / F : 0; // windows closed by this call
+    auto close_of = [&](long long k) { return ((k + 1) * F - prev0 + S - 1) / S - 1; }; // i_k (prev0 < fast: numerator > 0)
+    for (long long k0 = 0; k0 < K; k0 += 256) {
+        const long long k = k0 + tid;
+        int sum = 0;
+        if (k < K) {
+            const long long lo = k == 0 ? 0 : close_of(k - 1) + 1, hi = close_of(k);
+            for (long long i = lo; i <= hi; i++) sum += (int)res[i];
+            if (k == 0) sum += now0;
+        }
+        __syncthreads();
+        if (k < K) res[k] = (int16_t)(sum / div);
+    }
+    // what is left after the last closed window stays in now_lpr (indices >= K: none of them was overwritten)
+    const long long lo = K == 0 ? 0 : close_of(K - 1) + 1;
+    long long tail = 0;
+    for (long long i = lo + tid; i < len; i += 256) tail += res[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tail += __shfl_xor(tail, off);
+    if ((tid & 63) == 0) red[tid >> 6] = tail;
+    __syncthreads();
+    if (tid == 0) {
+        tail = red[0] + red[1] + red[2] + red[3];
+        lpr[0] = (int32_t)(tail + (K == 0 ? now0 : 0));
+        lpr[1] = (int32_t)(prev0 + len * S - K * F);
+        ps[3] = (int32_t)K; // result_len = i2
+    }
+}
+
+int launch_rtlfm_low_pass_real(int16_t *pcm, size_t nchan, size_t out_pitch, int rate_out, int rate_out2,
+                               int32_t *post_state, int32_t *lpr_state, hipStream_t s)
+{
+    if (!pcm || !post_state || !lpr_state) {
+        set_error("sdrx_rtlfm_low_pass_real_dev: null pointer");
+        return SDRX_EINVAL;
+    }
+    // slow > fast divides by fast / slow == 0 in the reference; rates beyond 2^30 overflow its int arithmetic
+    if (rate_out2 <= 0 || rate_out < rate_out2 || rate_out > (1 << 30)) {
+        set_error("sdrx_rtlfm_low_pass_real_dev: needs 0 < rate_out2 <= rate_out <= 2^30 (got %d, %d)", rate_out2, rate_out);
+        return SDRX_EINVAL;
+    }
+    if (nchan == 0) return SDRX_OK;
+    if (nchan > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
+    hipLaunchKernelGGL(rtlfm_low_pass_real_kernel, dim3((unsigned)nchan), dim3(256), 0, s, pcm, out_pitch, rate_out, rate_out2,
+                       post_state, lpr_state);
+    SDRX_HIP(hipGetLastError());
+    return SDRX_OK;
+}
+
 static int rtlfm_grid(size_t n, size_t nchan, int ds, dim3 &grid)
 {
     const size_t blocks = (n / (size_t)ds + 1 + 255) / 256; // prev_index < ds adds at most one output

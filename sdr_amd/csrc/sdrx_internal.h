@@ -90,6 +90,9 @@ int launch_rtlfm_full(const sdrx_rtlfm_params *p, const uint8_t *iq, size_t n, s
                       const int32_t *st_in, int32_t *st_out, int32_t *post_state, int64_t *work, int16_t *pcm,
                       size_t out_pitch, hipStream_t s);
 
+int launch_rtlfm_low_pass_real(int16_t *pcm, size_t nchan, size_t out_pitch, int rate_out, int rate_out2,
+                               int32_t *post_state, int32_t *lpr_state, hipStream_t s);
+
 // mod_kernels.hip
 int launch_am_modulate(const uint8_t *bits, size_t len, size_t nchan, size_t in_pitch, double *out, size_t len_mod,
                        size_t out_pitch, hipStream_t s);

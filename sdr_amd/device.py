@@ -221,6 +221,16 @@ class RtlFmFull(RtlFm):
         return m // self.params.post_downsample if self.params.post_downsample > 1 else m
 
 
+def rtlfm_low_pass_real(pcm, rate_out, rate_out2, post_state, lpr_state):
+    """low_pass_real (rtl_fm.c:341-361) in place on the rows of pcm (nchan, pitch) int16; post_state (nchan, 4) int32 as
+    RtlFmFull keeps it (row length at [:, 3], updated); lpr_state (nchan, 2) int32 = now_lpr, prev_lpr_index."""
+    assert pcm.dtype == torch.int16 and pcm.dim() == 2 and pcm.is_contiguous()
+    assert post_state.dtype == torch.int32 and lpr_state.dtype == torch.int32 and lpr_state.numel() == 2 * pcm.shape[0]
+    _lib.check(_lib.lib().sdrx_rtlfm_low_pass_real_dev(_ptr(pcm), pcm.shape[0], pcm.shape[1], int(rate_out), int(rate_out2),
+                                                       _ptr(post_state), _ptr(lpr_state), _stream()),
+               "sdrx_rtlfm_low_pass_real_dev")
+
+
 def deframe(bits, crc_enable=True, max_events=1024):
     """bits: (nchan, n) uint8 0/1 on the device.  Returns per channel a dict like the reference's loop would leave:
     events (pos, kind, len, crc as numpy arrays), payload (k, 250), counts; see sdrx_deframe_dev."""

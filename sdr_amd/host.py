@@ -69,6 +69,17 @@ class Filter:
         _lib.check(self._L.sdrx_fir_execute(self._h, _p(buf), n), "sdrx_fir_execute")
 
 
+def fir_execute_batch(filters, bufs, length=None):
+    """Filter::execute on many Filter objects at once (sdrx_fir_execute_batch): bufs[c] is filtered in place by
+    filters[c]; one staging block, one launch per filter design."""
+    nchan = len(filters)
+    assert len(bufs) == nchan
+    n = (bufs[0].size if nchan else 0) if length is None else int(length)
+    hs = (C.c_void_p * max(nchan, 1))(*[f._h for f in filters])
+    ps = (C.c_void_p * max(nchan, 1))(*[_f64(b).ctypes.data for b in bufs])
+    _lib.check(_lib.lib().sdrx_fir_execute_batch(hs, ps, n, nchan), "sdrx_fir_execute_batch")
+
+
 class AM:
     """AM<RADIO_DATA_TYPE>, streams/AM.h:19-81."""
 

@@ -125,6 +125,8 @@ def lib():
     L.orc_rtlfm_chain.restype = _sz
     L.orc_rtlfm_full.argtypes = [_u8, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32, _i32, _i16, _sz, C.c_int]
     L.orc_rtlfm_full.restype = _sz
+    L.orc_rtlfm_low_pass_real.argtypes = [_i16, C.c_int, C.c_int, C.c_int, _i32]
+    L.orc_rtlfm_low_pass_real.restype = C.c_int
     L.orc_decimate.argtypes = [_f64, _sz, _sz]
     L.orc_decimate.restype = _sz
     L.orc_upsample_fill_w_zeros.argtypes = [_f64, _sz, _f64, _sz, C.c_double]

@@ -1370,3 +1370,96 @@ def test_config1_at_its_stated_size():
         m = L.orc_chain_fir_am(taps, 64, np.zeros(63), np.zeros(63), re, im, n, ds, want)
         assert m == bits.shape[1] and np.array_equal(bits[0].cpu().numpy(), want[:m]), ds
         assert 0.2 < want[:m].mean() < 0.8
+
+
+@pytest.mark.parametrize("rate_out,rate_out2", [(170000, 32000), (48000, 48000), (240000, 24000), (100, 33), (7, 3), (1000000, 1)])
+def test_rtlfm_low_pass_real_vs_oracle(rate_out, rate_out2):
+    """low_pass_real (rtl_fm.c:341-361) behind sdrx_rtlfm_full_dev's rows: 70 channels of different lengths (0, 1,
+    shorter than one window, thousands), three calls with now_lpr / prev_lpr_index carried; rows bit for bit (the whole
+    buffer: what the in-place walk leaves behind its output included), result_len and the two state words.  Literal
+    restatement as the checker (parity unpinned: rtl_fm.c is not buildable here)."""
+    rng = np.random.default_rng(rate_out + rate_out2)
+    nchan, cap = 70, 5000
+    lpr = np.zeros((nchan, 2), dtype=np.int32)
+    d_lpr = torch.zeros(nchan, 2, dtype=torch.int32, device="cuda")
+    for call in range(3):
+        lens = rng.integers(0, cap + 1, nchan)
+        lens[:4] = [0, 1, 2, cap]
+        rows = rng.integers(-32768, 32768, (nchan, cap)).astype(np.int16)
+        post = np.zeros((nchan, 4), dtype=np.int32)
+        post[:, 3] = lens
+        d_rows, d_post = torch.tensor(rows, device="cuda"), torch.tensor(post, device="cuda")
+        device.rtlfm_low_pass_real(d_rows, rate_out, rate_out2, d_post, d_lpr)
+        for c in range(nchan):
+            post[c, 3] = L.orc_rtlfm_low_pass_real(rows[c], int(lens[c]), rate_out, rate_out2, lpr[c])
+        assert np.array_equal(d_rows.cpu().numpy(), rows), call
+        assert np.array_equal(d_post.cpu().numpy(), post) and np.array_equal(d_lpr.cpu().numpy(), lpr), call
+    rc = _lib.lib().sdrx_rtlfm_low_pass_real_dev(C.c_void_p(d_rows.data_ptr()), nchan, cap, 100, 101, C.c_void_p(d_post.data_ptr()),
+                                                 C.c_void_p(d_lpr.data_ptr()), None)
+    assert rc == -1  # rate_out2 > rate_out divides by zero in the reference: rejected
+
+
+def test_fir_execute_batch_host_layer():
+    """sdrx_fir_execute_batch: many Filter objects in one call (one staging block, one launch per design).  Seven
+    objects -- four of one design, two of another, one with its error flag set -- three calls of ragged lengths; every
+    buffer equals the same object run alone through the oracle, shift registers carried; afterwards the objects still
+    work one at a time (their own state rows were updated)."""
+    rng = np.random.default_rng(12)
+    specs = [(O.LPF, 64, 2.4e6, 1.0e5, None)] * 3 + [(O.HPF, 51, 2.0e6, 3.0e5, None), (O.LPF, 64, 2.4e6, 1.0e5, None),
+                                                     (O.HPF, 51, 2.0e6, 3.0e5, None), (O.LPF, 1001, 2.0e6, 1.0e5, None)]
+    fs = [host.Filter(*sp) for sp in specs]
+    os_ = [O.Fir(*sp) for sp in specs]
+    assert fs[-1].get_error_flag() == -3
+    for n in (1, 777, 5000):
+        xs = [rng.integers(-127, 128, n).astype(np.float64) + rng.uniform(-0.5, 0.5, n) for _ in specs]
+        bufs = [x.copy() for x in xs]
+        host.fir_execute_batch(fs, bufs)
+        for c, (o, x) in enumerate(zip(os_, xs)):
+            assert np.array_equal(bufs[c], o.execute(x, fast=True)), (n, c)
+    x = rng.uniform(-100, 100, 300)
+    a = x.copy()
+    fs[1].execute(a)
+    assert np.array_equal(a, os_[1].execute(x, fast=True))
+    with pytest.raises(RuntimeError):
+        host.fir_execute_batch([fs[0], fs[0]], [np.zeros(4), np.zeros(4)])  # one object, two rows of state: refused
+
+
+def test_legacy_entry_points_from_concurrent_radio_threads():
+    """The receiver runs one demodulating host thread per RADIO_ID (rtlsdr_receiver.cpp:191-194, 2016-2019): four threads
+    call am_gpu_demodulation / fm_gpu_demodulation with their own RADIO_ID at once, the FM threads with two different
+    samples-per-bit so that the shared mark / space tables are rebuilt under them.  Every result equals the oracle's."""
+    import threading
+    Lx = _lib.lib()
+    n, radios, rounds = 200000, 4, 6
+    Lx.am_gpu_initialize(n, radios)
+    Lx.fm_gpu_initialize(radios, n, 2000000, 100, 19000.0, 20000.0)
+    rng = np.random.default_rng(13)
+    res = [rng.integers(-127, 128, n).astype(np.float64) for _ in range(radios)]
+    ims = [rng.integers(-127, 128, n).astype(np.float64) for _ in range(radios)]
+    want_am = [O.am_demodulate(res[r], ims[r], 1 + r) for r in range(radios)]
+    ds_of = [100, 50, 100, 50]
+    want_fm = [O.fm_demodulate(2000000.0, 19000.0, 20000.0, res[r], ds_of[r]) for r in range(radios)]
+    errors = []
+
+    def radio_thread(r):
+        try:
+            for _ in range(rounds):
+                out = np.zeros(n, dtype=np.uint8)
+                Lx.am_gpu_demodulation(r, res[r].ctypes.data, ims[r].ctypes.data, out.ctypes.data, n, 1 + r)
+                if not np.array_equal(out[: n // (1 + r)], want_am[r][: n // (1 + r)]):
+                    errors.append(("am", r))
+                out = np.zeros(n, dtype=np.uint8)
+                Lx.fm_gpu_demodulation(r, res[r].ctypes.data, ims[r].ctypes.data, out.ctypes.data, n, ds_of[r])
+                if not np.array_equal(out[: n // ds_of[r]], want_fm[r]):
+                    errors.append(("fm", r))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=radio_thread, args=(r,)) for r in range(radios)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    Lx.am_gpu_free()
+    Lx.fm_gpu_free()
+    assert not errors, errors
