@@ -121,6 +121,26 @@ int sdrx_fir_am_dev(const sdrx_fir_job *job);
 int sdrx_fir_fmdisc_dev(const sdrx_fir_job *job);
 size_t sdrx_fir_state_doubles(int num_taps); /* 2*(T-1)+2 */
 
+/*
+ * One radio delivers its stream in blocks (rtlsdr_receiver.cpp:1974-2116: one block per call), and a block of 2^18
+ * samples is a microsecond of GPU work behind several microseconds of launch: launch-bound.  A ring processes `chunks`
+ * consecutive chunks of ONE stream per launch call -- chunk k reads in0 + k * in_stride bytes, writes out0 + k * out_stride
+ * bytes, the Filter / discriminator state carried from chunk to chunk through the job's two state buffers and from
+ * call to call.  use_graph = 1 (recommended): chunks that abut in memory (strides = chunk sizes, n a multiple of decim)
+ * are filtered by ONE launch over the whole ring -- a ring of chunks of one stream is one longer block of it --, other
+ * rings replay a HIP graph captured once at creation; 2: always the graph; 0: the chunk launches issued one by one.
+ * Measured (cfg2 chain, 2^18-sample chunks): 5.8 us per chunk one by one, 5.6 us from the graph (the cost is the GPU's
+ * own latency between dependent launches), 0.78 us in one launch.  epilogue: 0 sdrx_fir_dev, 1 sdrx_fir_am_dev,
+ * 2 sdrx_fir_fmdisc_dev.  Results are those of the plain calls, bit for bit.  sdrx_fir_ring_state(): which of the two
+ * state buffers holds the stream's state now.
+ */
+typedef struct sdrx_fir_ring sdrx_fir_ring_t;
+sdrx_fir_ring_t *sdrx_fir_ring_create(const sdrx_fir_job *chunk0, int epilogue, size_t chunks, size_t in_stride,
+                                      size_t out_stride, int use_graph);
+int sdrx_fir_ring_launch(sdrx_fir_ring_t *r, void *stream);
+const void *sdrx_fir_ring_state(const sdrx_fir_ring_t *r);
+void sdrx_fir_ring_destroy(sdrx_fir_ring_t *r);
+
 /* AM<T>::demodulate (AM.h:63-77) / kernel_am_demod (am.cu:72-81): out[k] = |x[k*ds]| >= 80 */
 int sdrx_am_demod_dev(const double *re, const double *im, uint8_t *out, size_t n, size_t ds, void *stream);
 /* ones/zeros count (rtlsdr_receiver.cpp:2063-2074, ones_zeros.cu:28-52): *count (device int32, zeroed by the call) */

@@ -66,6 +66,10 @@ SIGNATURES = {
     "sdrx_fir_am_dev": (C.c_int, [C.POINTER(FirJob)]),
     "sdrx_fir_fmdisc_dev": (C.c_int, [C.POINTER(FirJob)]),
     "sdrx_fir_state_doubles": (_sz, [C.c_int]),
+    "sdrx_fir_ring_create": (_vp, [C.POINTER(FirJob), C.c_int, _sz, _sz, _sz, C.c_int]),
+    "sdrx_fir_ring_launch": (C.c_int, [_vp, _vp]),
+    "sdrx_fir_ring_state": (_vp, [_vp]),
+    "sdrx_fir_ring_destroy": (None, [_vp]),
     "sdrx_am_demod_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "sdrx_ones_zeros_dev": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "sdrx_ones_zeros_confidence_dev": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_int32, _vp, _vp]),

@@ -760,6 +760,131 @@ extern "C" double sdrx_fir_do_sample(sdrx_fir_t *f, double x)
     return v;
 }
 
+// ---- a ring of chunk launches of ONE stream, captured once in a HIP graph (device layer; see sdrx.h)
+struct sdrx_fir_ring {
+    sdrx_fir_job job; // chunk 0
+    FirEpilogue epi = EPI_STORE;
+    size_t chunks = 0, in_stride = 0, out_stride = 0;
+    int mode = 1;            // 0: chunk launches issued one by one, 1: one launch over the whole (contiguous) ring, 2: HIP graph
+    int parity = 0;          // which of the two state buffers holds the stream's state now
+    hipStream_t cap = nullptr;
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+};
+
+static int ring_issue(const sdrx_fir_ring *r, int parity, hipStream_t st)
+{
+    for (size_t k = 0; k < r->chunks; k++) {
+        sdrx_fir_job j = r->job;
+        j.in0 = (const char *)r->job.in0 + k * r->in_stride;
+        if (r->job.in1) j.in1 = (const char *)r->job.in1 + k * r->in_stride;
+        j.out0 = (char *)r->job.out0 + k * r->out_stride;
+        if (r->job.out1) j.out1 = (char *)r->job.out1 + k * r->out_stride;
+        const bool flip = ((k + (size_t)parity) & 1) != 0;
+        j.state_in = flip ? (const void *)r->job.state_out : r->job.state_in;
+        j.state_out = flip ? (void *)r->job.state_in : r->job.state_out;
+        j.stream = st;
+        int rc = launch_fir(&j, r->epi);
+        if (rc) return rc;
+    }
+    return SDRX_OK;
+}
+
+extern "C" void sdrx_fir_ring_destroy(sdrx_fir_ring_t *r)
+{
+    if (!r) return;
+    for (int p = 0; p < 2; p++) {
+        if (r->exec[p]) (void)hipGraphExecDestroy(r->exec[p]);
+        if (r->graph[p]) (void)hipGraphDestroy(r->graph[p]);
+    }
+    if (r->cap) (void)hipStreamDestroy(r->cap);
+    delete r;
+}
+
+extern "C" sdrx_fir_ring_t *sdrx_fir_ring_create(const sdrx_fir_job *chunk0, int epilogue, size_t chunks, size_t in_stride,
+                                                 size_t out_stride, int use_graph)
+{
+    if (!chunk0 || chunks == 0 || epilogue < 0 || epilogue > 2 || !chunk0->state_in || !chunk0->state_out) {
+        set_error("sdrx_fir_ring_create: bad argument");
+        return nullptr;
+    }
+    sdrx_fir_ring *r = new sdrx_fir_ring();
+    r->job = *chunk0;
+    r->epi = (FirEpilogue)epilogue;
+    r->chunks = chunks;
+    r->in_stride = in_stride;
+    r->out_stride = out_stride;
+    // A ring whose chunks abut in memory IS one longer block of the same stream (Filter::execute carries its shift
+    // register, filt.cpp:256-259; the decimation phase continues when the chunk length is a multiple of D; rotate_90
+    // restarts every 4 samples): one launch over chunks * n samples gives the chunked results bit for bit, without
+    // the ~5.6 us the GPU spends between two dependent launches (a graph does not remove that: measured 5.57 us per
+    // chunk replayed against 5.81 us issued one by one).
+    const size_t in_elem = chunk0->layout == SDRX_IQ_U8 ? 2 : (chunk0->dtype == SDRX_F32 ? sizeof(float) : sizeof(double)) *
+                                                                  (chunk0->layout == SDRX_IQ_INTERLEAVED ? 2 : 1);
+    const size_t D = chunk0->decim ? chunk0->decim : 1, n_out1 = chunk0->n_out ? chunk0->n_out : (chunk0->n + D - 1) / D;
+    const size_t fp = chunk0->dtype == SDRX_F32 ? sizeof(float) : sizeof(double);
+    const size_t out_elem = epilogue == EPI_AM ? 1 : ((epilogue == EPI_STORE && chunk0->layout != SDRX_REAL && !chunk0->out1) ? 2 * fp : fp);
+    const bool contiguous = chunk0->nchan == 1 && in_stride == chunk0->n * in_elem && out_stride == n_out1 * out_elem &&
+                            chunk0->n % D == 0 && chunk0->n_out == 0 && (chunk0->layout != SDRX_IQ_U8 || chunk0->n % 4 == 0);
+    r->mode = use_graph == 0 ? 0 : ((use_graph == 1 && contiguous) ? 1 : 2);
+    if (r->mode == 1) { // one job over the ring
+        r->job.n = chunk0->n * chunks;
+        r->job.in_pitch = r->job.n;
+        r->job.out_pitch = n_out1 * chunks;
+        r->chunks = 1;
+        return r;
+    }
+    if (r->mode == 0) return r;
+    // One launch outside the capture, on throw-away state rows: whatever the launcher creates on the first use of a
+    // tile geometry (its window-offset table, the kernel's LDS attribute) exists before the capture begins.  It writes
+    // chunk 0's output slot, which the first replay overwrites.
+    const size_t st_bytes = chunk0->nchan * chunk0->state_pitch * (chunk0->dtype == SDRX_F32 ? sizeof(float) : sizeof(double));
+    void *tmp = nullptr;
+    bool ok = hipMalloc(&tmp, 2 * st_bytes + 256) == hipSuccess && hipMemset(tmp, 0, 2 * st_bytes + 256) == hipSuccess;
+    if (ok) {
+        sdrx_fir_job w = *chunk0;
+        w.state_in = tmp;
+        w.state_out = (char *)tmp + st_bytes;
+        w.stream = nullptr;
+        ok = launch_fir(&w, r->epi) == SDRX_OK && hipDeviceSynchronize() == hipSuccess;
+    }
+    if (tmp) (void)hipFree(tmp);
+    ok = ok && hipStreamCreateWithFlags(&r->cap, hipStreamNonBlocking) == hipSuccess;
+    // odd ring lengths leave the state in the other buffer after a replay: one graph per starting parity
+    for (int p = 0; ok && p < ((chunks & 1) ? 2 : 1); p++) {
+        ok = hipStreamBeginCapture(r->cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        const int rc = ok ? ring_issue(r, p, r->cap) : SDRX_EHIP;
+        ok = hipStreamEndCapture(r->cap, &r->graph[p]) == hipSuccess && rc == SDRX_OK && ok;
+        ok = ok && hipGraphInstantiate(&r->exec[p], r->graph[p], nullptr, nullptr, 0) == hipSuccess;
+    }
+    if (!ok) {
+        if (!*sdrx_last_error()) set_error("sdrx_fir_ring_create: graph capture failed");
+        sdrx_fir_ring_destroy(r);
+        return nullptr;
+    }
+    return r;
+}
+
+extern "C" int sdrx_fir_ring_launch(sdrx_fir_ring_t *r, void *stream)
+{
+    if (!r) return SDRX_EINVAL;
+    const int p = (r->chunks & 1) ? r->parity : 0;
+    if (r->mode == 2) SDRX_HIP(hipGraphLaunch(r->exec[p], (hipStream_t)stream));
+    else {
+        int rc = ring_issue(r, r->parity, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    if (r->chunks & 1) r->parity ^= 1;
+    return SDRX_OK;
+}
+
+extern "C" const void *sdrx_fir_ring_state(const sdrx_fir_ring_t *r)
+{
+    if (!r) return nullptr;
+    // after an even number of launches in all the state is where chunk 0 reads it from
+    return r->parity ? (const void *)r->job.state_out : r->job.state_in;
+}
+
 // ---- AM / FM on host buffers
 struct HostCtx { // one per thread: a stream and staging for the stateless host-layer calls
     hipStream_t stream = nullptr;

@@ -109,6 +109,40 @@ class FirChain:
                   angle.shape[1], fast_fma)
 
 
+class FirRing:
+    """`chunks` consecutive chunk launches of one FirChain's stream, replayed from a HIP graph (sdrx_fir_ring_*).
+    x: (chunks, n, 2) interleaved complex (or (chunks, n) real) ring of input chunks; out: (chunks, n_out_per_chunk)
+    ring of outputs; epilogue: "fir" | "am" | "fmdisc".  The chain must have nchan == 1; its state is the stream's.
+    use_graph: 1 = one launch over a contiguous ring, else a HIP graph; 2 = always the graph; 0 = launches one by one."""
+
+    def __init__(self, chain, x, out, epilogue="fmdisc", use_graph=1):
+        assert chain.nchan == 1 and x.is_contiguous() and out.is_contiguous() and x.shape[0] == out.shape[0]
+        self.chain, self.x, self.out = chain, x, out
+        layout, in0, in1, n, pitch = chain._inputs(x[0:1])
+        assert in1 is None
+        j = chain._job(layout, x[0:1], None, n, pitch, out[0:1], None, out.shape[1], False, 0)
+        j.stream = None
+        self.L = _lib.lib()
+        self.h = self.L.sdrx_fir_ring_create(C.byref(j), {"fir": 0, "am": 1, "fmdisc": 2}[epilogue], x.shape[0],
+                                             x.stride(0) * x.element_size(), out.stride(0) * out.element_size(),
+                                             int(use_graph))
+        if not self.h:
+            raise RuntimeError("sdrx_fir_ring_create failed: " + self.L.sdrx_last_error().decode())
+        self._state0 = chain.state[chain.cur].data_ptr()
+
+    def launch(self):
+        _lib.check(self.L.sdrx_fir_ring_launch(self.h, _stream()), "sdrx_fir_ring_launch")
+        self.chain.cur = 0 if self.L.sdrx_fir_ring_state(self.h) == self.chain.state[0].data_ptr() else 1
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.sdrx_fir_ring_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 def am_demod(re, im, out, ds):
     _lib.check(_lib.lib().sdrx_am_demod_dev(_ptr(re), _ptr(im), _ptr(out), re.numel(), int(ds), _stream()),
                "sdrx_am_demod_dev")

@@ -1463,3 +1463,41 @@ def test_legacy_entry_points_from_concurrent_radio_threads():
     Lx.am_gpu_free()
     Lx.fm_gpu_free()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("chunks,use_graph", [(8, 2), (5, 2), (5, 0), (1, 2), (8, 1), (5, 1)])
+@pytest.mark.parametrize("epilogue,D", [("fmdisc", 10), ("am", 1), ("fir", 4)])
+def test_fir_ring_replays_equal_one_long_call(epilogue, D, chunks, use_graph):
+    """sdrx_fir_ring_*: `chunks` chunks of one stream per call: replayed from a HIP graph (use_graph 2; odd ring lengths
+    alternate two graphs, one per state-buffer parity), issued one by one (0), or -- the ring being contiguous -- as one
+    launch over the whole ring (1).  Three replays over fresh data == the same 3 * chunks * n samples in ONE call
+    of the plain entry point on a second chain, bit for bit (Filter::execute is a stream: filt.cpp:256-259), final
+    state included; the systolic, the workgroup-tile (first-use table creation before the capture) kernels."""
+    err, taps = O.fir_design(O.LPF, 64, 2.4e6, 1.0e5)
+    n = 4000
+    n_out = (n + D - 1) // D
+    g = torch.Generator(device="cuda").manual_seed(chunks * 100 + D)
+    ring_x = torch.zeros(chunks, n, 2, dtype=torch.float64, device="cuda")
+    odt = torch.uint8 if epilogue == "am" else torch.float64
+    width = 2 * n_out if epilogue == "fir" else n_out  # "fir" stores interleaved complex
+    ring_o = torch.zeros(chunks, width, dtype=odt, device="cuda")
+    ch = device.FirChain(taps, 1, D)
+    ring = device.FirRing(ch, ring_x, ring_o, epilogue, use_graph)
+    ref = device.FirChain(taps, 1, D)
+    for rep in range(3):
+        data = torch.randint(-127, 128, (chunks, n, 2), generator=g, device="cuda").to(torch.float64)
+        ring_x.copy_(data)
+        ring.launch()
+        whole = data.view(1, chunks * n, 2)
+        if epilogue == "fmdisc":
+            want = torch.zeros(1, chunks * n_out, dtype=torch.float64, device="cuda")
+            ref.fir_fmdisc(whole, want)
+        elif epilogue == "am":
+            want = torch.zeros(1, chunks * n_out, dtype=torch.uint8, device="cuda")
+            ref.fir_am(whole, want)
+        else:
+            want = torch.zeros(1, chunks * n_out, 2, dtype=torch.float64, device="cuda")
+            ref.fir(whole, want, None)
+        torch.cuda.synchronize()
+        assert torch.equal(ring_o.view(-1), want.view(-1)), (rep, epilogue, chunks)
+        assert torch.equal(ch.state[ch.cur], ref.state[ref.cur]), (rep, "carried state")
