@@ -108,6 +108,10 @@ typedef struct sdrx_fir_job {
     int u8_flags;             /* SDRX_IQ_U8 only: SDRX_U8_SIGNED_CHAR | SDRX_U8_ROTATE90 */
     double u8_bias;           /* SDRX_IQ_U8 only: x = (T)byte - u8_bias (127: rtlsdr_receiver.cpp:1587-1588, rtl_fm.c:812-815;
                                  127.4 with SDRX_U8_SIGNED_CHAR: Baseband_Stream.cpp:128-148) */
+    size_t n_before;          /* 0 (default): x[c][i < 0] is the carried state.  Otherwise the block is a slice of a longer
+                                 resident buffer: n_before >= num_taps - 1 (+ decim for sdrx_fir_fmdisc_dev) samples of the
+                                 same channel lie in front of in0 and ARE the history (state_in is not read): a stream
+                                 tiled in time, every tile its own launch, gives the one-launch results */
 } sdrx_fir_job;
 
 /* Filter::execute (filt.cpp:267-273) on 1 rail (out0) or on I and Q (out0, out1), optionally

@@ -59,6 +59,15 @@ SDRX_HD double sdrx_kcos(double r)
     return w + (((1.0 - w) - hz) + z * p);
 }
 
+/* "does any lane of the wave take the rare path": on the GPU a wave-uniform test (one scalar branch, no divergence,
+ * nothing executed when no lane needs it); on a CPU the plain condition.  Lanes that do not need the rare path keep
+ * their values through selects inside it, so the result of every lane is the same either way. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SDRX_ANY_LANE(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+#else
+#define SDRX_ANY_LANE(c) (c)
+#endif
+
 /* s = sin(x), c = cos(x).  Same bits on every IEEE-754 target. */
 SDRX_HD void sdrx_sincos(double x, double *s, double *c)
 {
@@ -68,28 +77,37 @@ SDRX_HD void sdrx_sincos(double x, double *s, double *c)
                  P3 = 2.02226624871116645580e-21, P3T = 8.47842766036889956997e-32;
     /* 2^20 * 2*pi split in three pieces with 26 trailing zero bits each (coarse stage for huge |x|) */
     const double M1 = 6588397.0, M2 = 0.31666114181280136 /* 0x1.4442d18p-2 */, M3 = 2.56827048412547e-10;
-    /* Straight-line on purpose (selects, no branches): inside the PSK carrier loop this runs next to
-     * the independent timing-loop arithmetic of the following sample, and one basic block lets the
-     * compiler interleave the two dependency chains.  Values are those of the branching form. */
+    /* The common path (|x| <= 1.5e6, finite) is straight-line: inside the PSK carrier loop this is the longest part of
+     * a serial chain.  Huge, infinite and NaN arguments (a loop that has run away) are handled under two wave-uniform
+     * tests that cost one scalar branch each when no lane needs them. */
     const double x0 = x;
     const double ax = x < 0.0 ? -x : x;
-    const int bad = !(ax < 1.0e300); /* inf / nan / absurd */
-    const int big = ax > 1.5e6;
-    const double q = rint(x * 1.5178198155583891e-07); /* 1/(2^20*2pi) */
-    const double xr = ((x - q * M1) - q * M2) - q * M3;
-    x = big ? xr : x;
+    const int rare = !(ax <= 1.5e6); /* huge, inf or nan */
+    int bad = 0;
+    if (SDRX_ANY_LANE(rare)) {
+        bad = !(ax < 1.0e300); /* inf / nan / absurd */
+        const int big = ax > 1.5e6;
+        const double q = rint(x * 1.5178198155583891e-07); /* 1/(2^20*2pi) */
+        const double xr = ((x - q * M1) - q * M2) - q * M3;
+        x = big ? xr : x;
+    }
     const double fn = rint(x * INV_PIO2);
     double r = ((x - fn * P1) - fn * P2) - fn * P3;
     r = r - fn * P3T;
-    const int k = bad ? 0 : ((int)fn & 3); /* |fn| < 2^23 whenever the result is used */
+    int k = (int)fn & 3; /* |fn| < 2^23 whenever the result is used */
     const double sr = sdrx_ksin(r);
     const double cr = sdrx_kcos(r);
+    if (SDRX_ANY_LANE(bad)) k = bad ? 0 : k;
     const double ss = (k & 1) ? cr : sr; /* k = 0: s =  sr, c =  cr */
     const double cc = (k & 1) ? sr : cr; /* k = 1: s =  cr, c = -sr */
-    const double sv = (k & 2) ? -ss : ss; /* k = 2: s = -sr, c = -cr */
-    const double cv = ((k + 1) & 2) ? -cc : cc; /* k = 3: s = -cr, c =  sr */
-    *s = bad ? x0 - x0 : sv;
-    *c = bad ? x0 - x0 : cv;
+    double sv = (k & 2) ? -ss : ss; /* k = 2: s = -sr, c = -cr */
+    double cv = ((k + 1) & 2) ? -cc : cc; /* k = 3: s = -cr, c =  sr */
+    if (SDRX_ANY_LANE(bad)) {
+        sv = bad ? x0 - x0 : sv;
+        cv = bad ? x0 - x0 : cv;
+    }
+    *s = sv;
+    *c = cv;
 }
 
 /* ---- atan / atan2 ------------------------------------------------------- */

@@ -28,6 +28,7 @@ class FirJob(C.Structure):
         ("state_in", _vp), ("state_out", _vp), ("state_pitch", _sz),
         ("out0", _vp), ("out1", _vp), ("out_pitch", _sz), ("n_out", _sz),
         ("stream", _vp), ("dtype", C.c_int), ("u8_flags", C.c_int), ("u8_bias", C.c_double),
+        ("n_before", _sz),
     ]
 
 

@@ -78,6 +78,7 @@ Tuning &tuning()
         x.fir_lds_pad_kb = env_int("SDRX_FIR_LDS_PAD_KB", d.fir_lds_pad_kb);
         x.fir_nt = env_int("SDRX_FIR_NT", d.fir_nt);
         x.fir_lds_soft_kb = env_int("SDRX_FIR_LDS_SOFT_KB", d.fir_lds_soft_kb);
+        x.fir_ct = env_int("SDRX_FIR_CT", d.fir_ct);
         x.psk_split = env_int("SDRX_PSK_SPLIT", d.psk_split);
         x.psk_overlap = env_int("SDRX_PSK_OVERLAP", d.psk_overlap);
         x.iir_cw = env_int("SDRX_IIR_CW", d.iir_cw);
@@ -175,6 +176,7 @@ extern "C" int sdrx_tune(const char *name, const char *value)
     else if (strcmp(name, "SDRX_FIR_LDS_PAD_KB") == 0) t.fir_lds_pad_kb = dflt ? d.fir_lds_pad_kb : v;
     else if (strcmp(name, "SDRX_FIR_NT") == 0) t.fir_nt = dflt ? d.fir_nt : v;
     else if (strcmp(name, "SDRX_FIR_LDS_SOFT_KB") == 0) t.fir_lds_soft_kb = dflt ? d.fir_lds_soft_kb : v;
+    else if (strcmp(name, "SDRX_FIR_CT") == 0) t.fir_ct = dflt ? d.fir_ct : v;
     else if (strcmp(name, "SDRX_PSK_SPLIT") == 0) t.psk_split = dflt ? d.psk_split : v;
     else if (strcmp(name, "SDRX_PSK_OVERLAP") == 0) t.psk_overlap = dflt ? d.psk_overlap : v;
     else if (strcmp(name, "SDRX_IIR_CW") == 0) t.iir_cw = dflt ? d.iir_cw : v;
@@ -187,7 +189,7 @@ extern "C" int sdrx_tune(const char *name, const char *value)
 
 extern "C" const char *sdrx_last_kernel(void)
 {
-    static thread_local char buf[512];
+    static thread_local char buf[1536];
     static const char *const lay[] = {"REAL", "IQ_SPLIT", "IQ_INTERLEAVED", "IQ_U8"};
     static const char *const epi[] = {"EPI_STORE", "EPI_AM", "EPI_DISC"};
     const LastKernel &l = t_last_kernel;
@@ -200,6 +202,8 @@ extern "C" const char *sdrx_last_kernel(void)
             snprintf(one, sizeof(one), "fir_systolic_kernel<D=%d, %s, %s%s>", k.a, lay[k.b & 3], epi[k.c % 3], k.d ? ", fma" : "");
         else if (strcmp(k.family, "fir_tile_kernel") == 0)
             snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s%s>", k.a, lay[k.b & 3], epi[k.c % 3], k.d ? ", fma" : "");
+        else if (strcmp(k.family, "fir_tile_kernel_ct129x4") == 0)
+            snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s, T=129, D=4 compile-time>", k.a, lay[k.b & 3], epi[k.c % 3]);
         else if (strncmp(k.family, "psk_loops", 9) == 0)
             snprintf(one, sizeof(one), "%s<%s>", k.family, k.a == SDRX_BPSK ? "BPSK" : "QPSK");
         else if (strcmp(k.family, "psk_ambiguity_kernel") == 0)
@@ -349,26 +353,31 @@ static const size_t MF_T = 129, MF_STATE = 2 * (MF_T - 1) + 2;
 
 extern "C" size_t sdrx_psk_work_bytes(size_t n, size_t nchan)
 {
-    return align256(nchan * (n / 4) * 2 * sizeof(double)) + 2 * align256(nchan * MF_STATE * sizeof(double));
+    // matched-filter output | zero-history rows | throw-away state rows | the carrier loop's call-locals (block pipeline)
+    return align256(nchan * (n / 4) * 2 * sizeof(double)) + 2 * align256(nchan * MF_STATE * sizeof(double)) +
+           align256(nchan * 4 * sizeof(double));
 }
 
+// One piece of decode_pulseShape: outputs [0, n_out) of the block that starts at iq, n_before samples of the same
+// channels in front of it (0: the call's start, zero history: BPSK.cpp:267-268 re-pads with zeros on every call).
 static int mf_launch(const double *iq, size_t n, size_t nchan, size_t in_pitch, double *mf_iq, size_t mf_pitch,
                      double *zero_state, double *dummy_state, hipStream_t stream, int *offs_buf = nullptr,
-                     unsigned offs_cap = 0)
+                     unsigned offs_cap = 0, size_t n_before = 0, size_t n_out = (size_t)-1)
 {
     const double *taps = psk_mf_taps_dev();
     if (!taps) {
-        set_error("matched-filter taps upload failed");
+        set_error("matched-filter taps lookup failed");
         return SDRX_EHIP;
     }
-    if (n / 4 == 0) return SDRX_OK;
-    // decode_pulseShape re-pads with zeros on every call (BPSK.cpp:267-268): zero history, nothing carried
-    SDRX_HIP(hipMemsetAsync(zero_state, 0, nchan * MF_STATE * sizeof(double), stream));
+    if (n_out == (size_t)-1) n_out = n / 4; // memcpy of number_of_points/4 values: BPSK.cpp:292-293
+    if (n_out == 0) return SDRX_OK;
+    if (n_before == 0) SDRX_HIP(hipMemsetAsync(zero_state, 0, nchan * MF_STATE * sizeof(double), stream));
     sdrx_fir_job j;
     memset(&j, 0, sizeof(j));
     j.layout = SDRX_IQ_INTERLEAVED;
     j.in0 = iq;
     j.n = n;
+    j.n_before = n_before;
     j.nchan = nchan;
     j.in_pitch = in_pitch;
     j.taps = taps;
@@ -380,9 +389,89 @@ static int mf_launch(const double *iq, size_t n, size_t nchan, size_t in_pitch, 
     j.out0 = mf_iq;
     j.out1 = nullptr;
     j.out_pitch = mf_pitch;
-    j.n_out = n / 4; // memcpy of number_of_points/4 values: BPSK.cpp:292-293
+    j.n_out = n_out;
     j.stream = stream;
     return launch_fir(&j, EPI_STORE, offs_buf, offs_cap);
+}
+
+// ---- block pipeline of the demodulator.  The matched filter is bound by fp64 VALU throughput on every SIMD; the two
+// loops are 2 waves per 64 channels, each bound by its own instruction latency (a bank of 2^14 channels keeps a quarter
+// of the chip's wave slots busy, whatever it does).  Run one after the other they leave most of the machine idle in
+// turn.  A call is therefore cut in time into PSK_PIECES pieces: the matched filter of piece k+1 (caller's stream;
+// its history is the samples in front of it: sdrx_fir_job.n_before) runs beside the loops of piece k (a side stream
+// of the library, ordered by events); loop state carries from piece to piece exactly as from call to call.  Same
+// kernels, same arithmetic, same order per channel: results are bit-identical to the one-stream form.
+static const int PSK_PIECES = 4;
+struct PskPipe {
+    hipStream_t side = nullptr;
+    hipEvent_t ev[PSK_PIECES + 1] = {};
+    bool ready = false;
+};
+static std::mutex g_pipe_mu;
+static std::map<int, PskPipe> g_pipe;
+
+static PskPipe *psk_pipe_locked() // g_pipe_mu held; created on the first use on a device, kept until the process ends
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    PskPipe &p = g_pipe[dev];
+    if (!p.ready) {
+        bool ok = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; ok && k <= PSK_PIECES; k++) ok = hipEventCreateWithFlags(&p.ev[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) return nullptr;
+        p.ready = true;
+    }
+    return &p;
+}
+
+static int psk_demod_common(int kind, const double *iq, size_t n, size_t nchan, size_t in_pitch, sdrx_psk_state *states,
+                            uint8_t *out, size_t out_pitch, unsigned char *w, hipStream_t s, int *offs_buf, unsigned offs_cap,
+                            bool may_overlap)
+{
+    const size_t m = n / 4;
+    double *mf = (double *)w;
+    double *zst = (double *)(w + align256(nchan * m * 2 * sizeof(double)));
+    double *dst = (double *)((unsigned char *)zst + align256(nchan * MF_STATE * sizeof(double)));
+    double *carry = (double *)((unsigned char *)dst + align256(nchan * MF_STATE * sizeof(double)));
+    KernelChain kc;
+    const int want = tuning().psk_overlap;
+    // Pays only where the loops dominate (few channels, long blocks): there the matched filter hides behind them
+    // (2^12 channels x 2^14 samples: 1.63 -> 1.51 ms).  Where the two take similar time (2^14 x 2^12) the loop waves,
+    // sharing their SIMDs with matched-filter waves, slow down by as much as the overlap saves (0.74 -> 0.89 ms;
+    // profiles/r02_cfg3_overlap_trace.json), s_setprio and a high-priority queue notwithstanding: off by default there.
+    const bool overlap = may_overlap && want != 0 && m >= 512 && (want > 0 || (nchan <= (1u << 12) && m >= 2048));
+    if (!overlap) {
+        int rc = mf_launch(iq, n, nchan, in_pitch, mf, m, zst, dst, s, offs_buf, offs_cap);
+        if (rc) return rc;
+        rc = launch_psk_loops(kind, mf, m, nchan, m, states, out, out_pitch, 1, 1, s);
+        if (rc) return rc;
+        return launch_psk_ambiguity(kind, out, (m + 1) / 2, nchan, out_pitch, states, s);
+    }
+    std::lock_guard<std::mutex> lk(g_pipe_mu); // one call's events at a time
+    PskPipe *pp = psk_pipe_locked();
+    if (!pp) {
+        set_error("sdrx_psk_demod_dev: side stream / events could not be created");
+        return SDRX_EHIP;
+    }
+    const size_t m_piece = (((m + PSK_PIECES - 1) / PSK_PIECES) + 15) & ~(size_t)15; // whole ring blocks, even: /2 keeps 0, 2, ...
+    int k = 0;
+    for (size_t m0 = 0; m0 < m; m0 += m_piece, k++) {
+        const bool last = m0 + m_piece >= m;
+        const size_t mk = last ? m - m0 : m_piece;
+        int rc = mf_launch(iq + 2 * 4 * m0, last ? n - 4 * m0 : 4 * mk, nchan, in_pitch, mf + 2 * m0, m, zst, dst, s, offs_buf,
+                           offs_cap, 4 * m0, mk);
+        if (rc) return rc;
+        SDRX_HIP(hipEventRecord(pp->ev[k], s));
+        SDRX_HIP(hipStreamWaitEvent(pp->side, pp->ev[k], 0));
+        rc = launch_psk_loops(kind, mf + 2 * m0, mk, nchan, m, states, out + m0 / 2, out_pitch, 1, 1, pp->side, carry,
+                              (m0 ? 1 : 0) | (last ? 0 : 2));
+        if (rc) return rc;
+    }
+    int rc = launch_psk_ambiguity(kind, out, (m + 1) / 2, nchan, out_pitch, states, pp->side);
+    if (rc) return rc;
+    SDRX_HIP(hipEventRecord(pp->ev[PSK_PIECES], pp->side));
+    SDRX_HIP(hipStreamWaitEvent(s, pp->ev[PSK_PIECES], 0)); // everything behind the call on the caller's stream sees its results
+    return SDRX_OK;
 }
 
 extern "C" int sdrx_psk_demod_dev(int kind, const double *iq, size_t n, size_t nchan, size_t in_pitch,
@@ -392,18 +481,8 @@ extern "C" int sdrx_psk_demod_dev(int kind, const double *iq, size_t n, size_t n
         set_error("sdrx_psk_demod_dev: null pointer");
         return SDRX_EINVAL;
     }
-    KernelChain kc;
-    hipStream_t s = (hipStream_t)stream;
-    const size_t m = n / 4;
-    unsigned char *w = (unsigned char *)work;
-    double *mf = (double *)w;
-    double *zst = (double *)(w + align256(nchan * m * 2 * sizeof(double)));
-    double *dst = (double *)((unsigned char *)zst + align256(nchan * MF_STATE * sizeof(double)));
-    int rc = mf_launch(iq, n, nchan, in_pitch, mf, m, zst, dst, s);
-    if (rc) return rc;
-    rc = launch_psk_loops(kind, mf, m, nchan, m, states, out, out_pitch, 1, 1, s);
-    if (rc) return rc;
-    return launch_psk_ambiguity(kind, out, (m + 1) / 2, nchan, out_pitch, states, s);
+    return psk_demod_common(kind, iq, n, nchan, in_pitch, states, out, out_pitch, (unsigned char *)work, (hipStream_t)stream,
+                            nullptr, 0, true);
 }
 
 // ---- the one entry point that allocates nothing (no counterpart in the reference; see include/sdrx.h)
@@ -465,21 +544,11 @@ extern "C" int sdrx_psk_demod_noalloc_dev(int kind, const double *iq, size_t n, 
     unsigned char *base = nullptr;
     int rc = noalloc_setup(&base);
     if (rc) return rc;
-    KernelChain kc;
-    hipStream_t s = (hipStream_t)stream;
-    const size_t m = n / 4;
-    int *offs = (int *)base;
-    unsigned char *w = base + NOALLOC_OFFS_BYTES;
-    double *mf = (double *)w;
-    double *zst = (double *)(w + align256(nchan * m * 2 * sizeof(double)));
-    double *dst = (double *)((unsigned char *)zst + align256(nchan * MF_STATE * sizeof(double)));
-    // everything the kernels expect to start at zero is cleared by mf_launch (the zero-history rows); the rest of the
-    // array keeps the last call's contents and is overwritten before it is read
-    rc = mf_launch(iq, n, nchan, in_pitch, mf, m, zst, dst, s, offs, (unsigned)NOALLOC_OFFS_INTS);
-    if (rc) return rc;
-    rc = launch_psk_loops(kind, mf, m, nchan, m, states, out, out_pitch, 1, 1, s);
-    if (rc) return rc;
-    return launch_psk_ambiguity(kind, out, (m + 1) / 2, nchan, out_pitch, states, s);
+    // everything the kernels expect to start at zero is cleared by the matched-filter launch (the zero-history rows);
+    // the rest of the array keeps the last call's contents and is overwritten before it is read.  One stream, no
+    // block pipeline: its side stream and events would be created on first use.
+    return psk_demod_common(kind, iq, n, nchan, in_pitch, states, out, out_pitch, base + NOALLOC_OFFS_BYTES,
+                            (hipStream_t)stream, (int *)base, (unsigned)NOALLOC_OFFS_INTS, false);
 }
 
 // sdrx_psk_matched_filter_dev's zero / dummy state rows: one buffer per device, grown on demand.  The lock is held

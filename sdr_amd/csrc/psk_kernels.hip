@@ -155,6 +155,11 @@ template <int KIND> __device__ __forceinline__ int phase_step(PhaseState &p, dou
     }
 }
 
+// One reference call may be cut into several launches over consecutive pieces of the block (the block pipeline of
+// sdrx_psk_demod_dev).  The loop structs carry through `states` as they do from call to call; the three locals of
+// phase_shift_correction, which restart at 0 only once per CALL, carry through `carry` (4 doubles per channel).
+enum { PIECE_NOT_FIRST = 1, PIECE_NOT_LAST = 2 };
+
 // The two loops are each one long dependency chain per sample, but the timing loop of sample i+1
 // does not depend on the carrier loop of sample i: the kernel runs them one sample apart in the
 // same straight-line block (no branches inside: every conditional above is a select), so the
@@ -162,16 +167,19 @@ template <int KIND> __device__ __forceinline__ int phase_step(PhaseState &p, dou
 template <int KIND, bool TIMING, bool PHASE>
 __global__ void __launch_bounds__(64) psk_loops_kernel(double2 *__restrict__ mf, size_t m, size_t nchan, size_t pitch,
                                                        sdrx_psk_state *__restrict__ states, uint8_t *__restrict__ dec,
-                                                       size_t out_pitch)
+                                                       size_t out_pitch, double *__restrict__ carry, int piece)
 {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchan) return;
+    // latency-bound chains: when a throughput kernel (the next piece's matched filter) shares the SIMD, issue first
+    __builtin_amdgcn_s_setprio(3);
     sdrx_psk_state *st = states + c;
     TimingState t = {st->nco_delay, st->reg_mu, st->reg_Q, st->reg_I, st->mu_delay,
                      {st->iq_d[0], st->iq_d[1], st->iq_d[2], st->iq_d[3], st->iq_d[4]},
                      {st->ii_d[0], st->ii_d[1], st->ii_d[2], st->ii_d[3], st->ii_d[4]},
                      st->g1, st->g2, st->g3, st->g4, st->lf_x, st->lf_y};
     PhaseState p = {st->dds_delay, st->plf_x, st->plf_y, 0.0, 0.0, 0.0};
+    if (piece & PIECE_NOT_FIRST) { p.tr = carry[4 * c]; p.ti = carry[4 * c + 1]; p.temp = carry[4 * c + 2]; }
     double2 *x = mf + c * pitch;
     uint8_t *d = dec + c * out_pitch;
 
@@ -226,6 +234,7 @@ __global__ void __launch_bounds__(64) psk_loops_kernel(double2 *__restrict__ mf,
     }
     if constexpr (PHASE) {
         st->dds_delay = p.dds_delay; st->plf_x = p.plf_x; st->plf_y = p.plf_y;
+        if (piece & PIECE_NOT_LAST) { carry[4 * c] = p.tr; carry[4 * c + 1] = p.ti; carry[4 * c + 2] = p.temp; }
     }
 }
 
@@ -239,9 +248,11 @@ constexpr int SPLIT_KB = 16;
 template <int KIND>
 __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__restrict__ mf, size_t m, size_t nchan,
                                                               size_t pitch, sdrx_psk_state *__restrict__ states,
-                                                              uint8_t *__restrict__ dec, size_t out_pitch)
+                                                              uint8_t *__restrict__ dec, size_t out_pitch,
+                                                              double *__restrict__ carry, int piece)
 {
     __shared__ double2 ring[2][SPLIT_KB][64];
+    __builtin_amdgcn_s_setprio(3); // latency-bound chains: issue ahead of a throughput kernel sharing the SIMD
     const unsigned lane = threadIdx.x & 63;
     const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t c0 = (size_t)blockIdx.x * 64 + lane;
@@ -257,6 +268,7 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
                      {st->ii_d[0], st->ii_d[1], st->ii_d[2], st->ii_d[3], st->ii_d[4]},
                      st->g1, st->g2, st->g3, st->g4, st->lf_x, st->lf_y};
     PhaseState p = {st->dds_delay, st->plf_x, st->plf_y, 0.0, 0.0, 0.0};
+    if (piece & PIECE_NOT_FIRST) { p.tr = carry[4 * c]; p.ti = carry[4 * c + 1]; p.temp = carry[4 * c + 2]; }
     double2 nxt[SPLIT_KB];
     if (role == 0) {
 #pragma unroll
@@ -300,12 +312,18 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
         st->lf_x = t.lf_x; st->lf_y = t.lf_y;
     } else {
         st->dds_delay = p.dds_delay; st->plf_x = p.plf_x; st->plf_y = p.plf_y;
+        if (piece & PIECE_NOT_LAST) { carry[4 * c] = p.tr; carry[4 * c + 1] = p.ti; carry[4 * c + 2] = p.temp; }
     }
 }
 
 int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch, sdrx_psk_state *states,
-                     uint8_t *decisions, size_t out_pitch, int run_timing, int run_phase, hipStream_t s)
+                     uint8_t *decisions, size_t out_pitch, int run_timing, int run_phase, hipStream_t s, double *carry,
+                     int piece)
 {
+    if (piece && !carry) {
+        set_error("psk_loops: a piece of a call needs the carry rows");
+        return SDRX_EINVAL;
+    }
     if (!mf_iq || !states || (run_phase && !decisions) || (kind != SDRX_BPSK && kind != SDRX_QPSK)) {
         set_error("psk_loops: bad argument");
         return SDRX_EINVAL;
@@ -319,15 +337,15 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
     if (run_timing && run_phase && split) {
         if (kind == SDRX_BPSK)
             hipLaunchKernelGGL(psk_loops_split_kernel<SDRX_BPSK>, dim3((unsigned)blocks), dim3(128), 0, s,
-                               (const double2 *)mf_iq, m, nchan, mf_pitch, states, decisions, out_pitch);
+                               (const double2 *)mf_iq, m, nchan, mf_pitch, states, decisions, out_pitch, carry, piece);
         else
             hipLaunchKernelGGL(psk_loops_split_kernel<SDRX_QPSK>, dim3((unsigned)blocks), dim3(128), 0, s,
-                               (const double2 *)mf_iq, m, nchan, mf_pitch, states, decisions, out_pitch);
+                               (const double2 *)mf_iq, m, nchan, mf_pitch, states, decisions, out_pitch, carry, piece);
         SDRX_HIP(hipGetLastError());
         note_kernel("psk_loops_split_kernel", kind, 0, 0, 0);
         return SDRX_OK;
     }
-    typedef void (*fn_t)(double2 *, size_t, size_t, size_t, sdrx_psk_state *, uint8_t *, size_t);
+    typedef void (*fn_t)(double2 *, size_t, size_t, size_t, sdrx_psk_state *, uint8_t *, size_t, double *, int);
     fn_t fn;
     if (kind == SDRX_BPSK)
         fn = run_timing ? (run_phase ? psk_loops_kernel<SDRX_BPSK, true, true> : psk_loops_kernel<SDRX_BPSK, true, false>)
@@ -336,7 +354,7 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
         fn = run_timing ? (run_phase ? psk_loops_kernel<SDRX_QPSK, true, true> : psk_loops_kernel<SDRX_QPSK, true, false>)
                         : psk_loops_kernel<SDRX_QPSK, false, true>;
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(64), 0, s, (double2 *)mf_iq, m, nchan, mf_pitch, states, decisions,
-                       out_pitch);
+                       out_pitch, carry, piece);
     SDRX_HIP(hipGetLastError());
     note_kernel("psk_loops_kernel", kind, run_timing, run_phase, 0);
     return SDRX_OK;

@@ -39,6 +39,7 @@ struct Tuning {
     int fir_lds_pad_kb = 0;   // SDRX_FIR_LDS_PAD_KB: extra LDS per systolic workgroup (lowers the occupancy)
     int fir_nt = 256;         // SDRX_FIR_NT: lanes per workgroup tile
     int fir_lds_soft_kb = 64; // SDRX_FIR_LDS_SOFT_KB: preferred LDS per workgroup tile
+    int fir_ct = 1;           // SDRX_FIR_CT: 0 = never use the compile-time (T = 129, D = 4) instance of the tile kernel
     int psk_split = -1;       // SDRX_PSK_SPLIT: -1 auto, 0 one-wave loops, 1 two-wave loops
     int psk_overlap = -1;     // SDRX_PSK_OVERLAP: -1 auto, 0 one stream, 1 block pipeline on two streams
     int iir_cw = 0;           // SDRX_IIR_CW: rows per wave of the recurrences (0 = by bank size)
@@ -52,7 +53,7 @@ struct KernelNote {
     int a, b, c, d;     // family-specific template arguments
 };
 struct LastKernel {
-    KernelNote k[4];
+    KernelNote k[12];
     int n = 0;
     bool chain = false;
 };
@@ -61,7 +62,7 @@ inline void note_kernel(const char *family, int a = 0, int b = 0, int c = 0, int
 {
     LastKernel &l = t_last_kernel;
     if (!l.chain) l.n = 0;
-    if (l.n < 4) l.k[l.n++] = KernelNote{family, a, b, c, d};
+    if (l.n < 12) l.k[l.n++] = KernelNote{family, a, b, c, d};
 }
 struct KernelChain {
     KernelChain() { t_last_kernel.n = 0; t_last_kernel.chain = true; }
@@ -105,8 +106,11 @@ int launch_deframe(const uint8_t *bits, size_t n, size_t nchan, size_t in_pitch,
                    uint8_t *payloads, size_t max_events, uint64_t *summary, hipStream_t s);
 
 // psk_kernels.hip
+// carry / piece: one call cut into several launches over consecutive pieces (psk_kernels.hip: PIECE_NOT_FIRST = 1,
+// PIECE_NOT_LAST = 2); carry = nchan x 4 doubles.  A whole call in one launch: carry = nullptr, piece = 0.
 int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch, sdrx_psk_state *states,
-                     uint8_t *decisions, size_t out_pitch, int run_timing, int run_phase, hipStream_t s);
+                     uint8_t *decisions, size_t out_pitch, int run_timing, int run_phase, hipStream_t s,
+                     double *carry = nullptr, int piece = 0);
 int launch_psk_ambiguity(int kind, uint8_t *decisions, size_t m, size_t nchan, size_t out_pitch,
                          sdrx_psk_state *states, hipStream_t s);
 int launch_psk_ambiguity_hits(int kind, uint8_t *decisions, size_t m, size_t nchan, size_t out_pitch,

@@ -1501,3 +1501,92 @@ def test_fir_ring_replays_equal_one_long_call(epilogue, D, chunks, use_graph):
         torch.cuda.synchronize()
         assert torch.equal(ring_o.view(-1), want.view(-1)), (rep, epilogue, chunks)
         assert torch.equal(ch.state[ch.cur], ref.state[ref.cur]), (rep, "carried state")
+
+
+@pytest.mark.parametrize("kind,lk", [(O.QPSK, _lib.QPSK), (O.BPSK, _lib.BPSK)])
+def test_psk_block_pipeline_equals_the_one_stream_form(kind, lk, tune):
+    """sdrx_psk_demod_dev's block pipeline (a call cut in time into pieces: the matched filter of piece k+1 on the
+    caller's stream beside the loops of piece k on the library's side stream; the matched filter's history taken from the
+    samples in front of the piece, sdrx_fir_job.n_before; the carrier loop's call-locals carried from piece to piece):
+    forced on and forced off give the same decisions and states, both equal the oracle; ragged piece lengths (a block
+    that is no multiple of the piece size), two calls in a row, a call on a non-default stream."""
+    nchan = 9
+    for n in (4 * 2048, 4 * (2048 + 24) + 3, 4 * 513):
+        iqs = [psk_test_signal(kind, n // 8 + 1, seed=400 + c, phase_deg=50.0 * c, snr_db=17.0, timing_offset=c % 5)[: 2 * n]
+               for c in range(nchan)]
+        x = torch.tensor(np.stack([np.asarray(z).reshape(-1, 2) for z in iqs]), device="cuda")
+        res = {}
+        for force in (0, 1):
+            tune("SDRX_PSK_OVERLAP", force)
+            b = device.PskBank(lk, nchan, n)
+            outs = []
+            for call in range(2):
+                o = torch.zeros(nchan, b.n_dec, dtype=torch.uint8, device="cuda")
+                if call == 1:
+                    with torch.cuda.stream(torch.cuda.Stream()):
+                        b.demod(x, o)
+                    torch.cuda.synchronize()
+                else:
+                    b.demod(x, o)
+                outs.append(o.cpu().numpy())
+            chain = _lib.lib().sdrx_last_kernel().decode()
+            assert chain.count("fir_tile_kernel") == (4 if force else 1), chain
+            res[force] = (outs, b.states.cpu().numpy())
+        for a, bb in zip(res[0][0], res[1][0]):
+            assert np.array_equal(a, bb), (kind, n)
+        assert np.array_equal(res[0][1], res[1][1]), (kind, n)
+        for c in (0, nchan - 1):
+            st = O.psk_new(kind, math_mode=O.MATH_SHARED)
+            for call in range(2):
+                want = O.psk_demodulate(st, np.ascontiguousarray(x[c].cpu().numpy().reshape(-1)))
+                assert np.array_equal(res[1][0][call][c][: want.size].astype(np.float64), want), (kind, n, c, call)
+
+
+def test_fir_job_n_before_tiles_a_stream_in_time():
+    """sdrx_fir_job.n_before: a block that is a slice of a longer resident buffer takes its history from the samples in
+    front of it.  A stream cut into 5 ragged slices, each its own launch with n_before = its offset, reproduces the
+    one-launch outputs bit for bit: FIR store (tile kernel), decimating discriminator (systolic kernel, needs the
+    previous output as well), raw-byte input with rotate_90 (slices at multiples of 4)."""
+    err, taps = O.fir_design(O.LPF, 64, 2.4e6, 1.0e5)
+    n = 40000
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randint(-127, 128, (2, n, 2), generator=g, device="cuda").to(torch.float64)
+    raw = torch.randint(0, 256, (2, n, 2), generator=g, device="cuda").to(torch.uint8)
+    cuts = [0, 8000, 8040, 20000, 39000, n]  # multiples of 40: whole decimation groups and whole rotate_90 groups
+    Lx = _lib.lib()
+    for name, D, inp in (("fir", 1, x), ("fmdisc", 10, x), ("fir_u8_rot", 4, raw)):
+        n_out = (n + D - 1) // D
+        def outs():
+            return (torch.zeros(2, n_out, dtype=torch.float64, device="cuda"), torch.zeros(2, n_out, dtype=torch.float64, device="cuda"))
+        ch = device.FirChain(taps, 2, D)
+        if name == "fir_u8_rot":
+            ch.set_u8_conversion(127.4, signed_char=True, rotate90=True)
+        w0, w1 = outs()
+        if name == "fmdisc":
+            ch.fir_fmdisc(inp, w0)
+        else:
+            ch.fir(inp, w0, w1)
+        g0, g1 = outs()
+        ch2 = device.FirChain(taps, 2, D)
+        if name == "fir_u8_rot":
+            ch2.set_u8_conversion(127.4, signed_char=True, rotate90=True)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            layout = _lib.IQ_U8 if name == "fir_u8_rot" else _lib.IQ_INTERLEAVED
+            j = ch2._job(layout, inp, None, hi - lo, n, g0, None if name == "fmdisc" else g1, n_out, False, 0)
+            esz = inp.element_size() * 2
+            j.in0 = C.c_void_p(inp.data_ptr() + lo * esz)
+            j.out0 = C.c_void_p(g0.data_ptr() + (lo // D) * 8)
+            if name != "fmdisc":
+                j.out1 = C.c_void_p(g1.data_ptr() + (lo // D) * 8)
+            j.n_before = lo
+            fn = Lx.sdrx_fir_fmdisc_dev if name == "fmdisc" else Lx.sdrx_fir_dev
+            _lib.check(fn(C.byref(j)), name)
+            ch2.cur ^= 1
+        torch.cuda.synchronize()
+        assert torch.equal(g0, w0), name
+        if name != "fmdisc":
+            assert torch.equal(g1, w1), name
+        assert torch.equal(ch2.state[ch2.cur], ch.state[ch.cur]), (name, "state after the last slice")
+    j = ch2._job(_lib.IQ_INTERLEAVED, x, None, 100, n, g0, g1, n_out, False, 0)
+    j.n_before = 10  # shorter than the filter's history: refused
+    assert Lx.sdrx_fir_dev(C.byref(j)) == -1
