@@ -8,9 +8,9 @@
  * ocml on the GPU do not return bit-identical results for those, and the
  * loops feed hard decisions, so the device path and its CPU checker must use
  * ONE definition.  Everything below is built only from IEEE-754 +,-,*,/ ,
- * rint and comparisons, evaluated in source order; compile it with
- * -ffp-contract=off on every target (gcc for the host, hipcc for gfx950) and
- * the two sides agree to the last bit.  Accuracy against libm: <= 2 ulp on
+ * fma (written out, in sincos), rint and comparisons, evaluated in source
+ * order; compile it with -ffp-contract=off on every target (gcc for the
+ * host, hipcc for gfx950) and the two sides agree to the last bit.  Accuracy against libm: <= 2 ulp on
  * the reduced range, |x| < 1.6e6 for sincos (the oracle's libm mode measures
  * the distance; see tests/test_oracle_golden.py).
  *
@@ -33,16 +33,24 @@
 
 /* ---- sincos ------------------------------------------------------------- */
 
+/* fused multiply-add, one rounding: an IEEE-754 operation like the others (v_fma_f64 on the GPU, libm's correctly
+ * rounded fma() or a hardware FMA on a host): the same bits everywhere.  Written out where it is meant; the rest of
+ * the file stays uncontracted (-ffp-contract=off). */
+#define SDRX_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
 /* sin(r) on |r| <= pi/4 */
 SDRX_HD double sdrx_ksin(double r)
 {
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double z = r * r;
-    double p = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    double v = z * r;
-    return r + v * (S1 + z * p);
+    const double z = r * r;
+    double p = SDRX_FMA(z, S6, S5);
+    p = SDRX_FMA(z, p, S4);
+    p = SDRX_FMA(z, p, S3);
+    p = SDRX_FMA(z, p, S2);
+    p = SDRX_FMA(z, p, S1);
+    return SDRX_FMA(z * r, p, r);
 }
 
 /* cos(r) on |r| <= pi/4 */
@@ -51,63 +59,60 @@ SDRX_HD double sdrx_kcos(double r)
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double z = r * r;
-    double p = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-    double hz = 0.5 * z;
-    double w = 1.0 - hz;
-    /* (1 - hz) - w is the rounding error of w, recovered exactly */
-    return w + (((1.0 - w) - hz) + z * p);
+    const double z = r * r;
+    double p = SDRX_FMA(z, C6, C5);
+    p = SDRX_FMA(z, p, C4);
+    p = SDRX_FMA(z, p, C3);
+    p = SDRX_FMA(z, p, C2);
+    p = SDRX_FMA(z, p, C1);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    /* (1 - w) - hz is the rounding error of w, recovered exactly */
+    return w + SDRX_FMA(z * z, p, (1.0 - w) - hz);
 }
 
-/* "does any lane of the wave take the rare path": on the GPU a wave-uniform test (one scalar branch, no divergence,
- * nothing executed when no lane needs it); on a CPU the plain condition.  Lanes that do not need the rare path keep
- * their values through selects inside it, so the result of every lane is the same either way. */
-#if defined(__HIP_DEVICE_COMPILE__)
-#define SDRX_ANY_LANE(c) (__builtin_amdgcn_ballot_w64(c) != 0)
-#else
-#define SDRX_ANY_LANE(c) (c)
-#endif
+/* The common case, straight-line: s = sin(x), c = cos(x) for |x| <= 1.5e6.  Returns nonzero -- and leaves
+ * unspecified finite-or-not values in *s, *c -- for every other x (huge, infinite, NaN): the caller then takes
+ * sdrx_sincos_rare.  The PSK carrier loop, where this is the longest part of a serial chain, runs a block of samples
+ * on this alone, ORs the flags, and repeats the block through sdrx_sincos if any was set (it never is unless a loop
+ * has run away). */
+SDRX_HD int sdrx_sincos_core(double x, double *s, double *c)
+{
+    const double INV_PIO2 = 6.36619772367581382433e-01;
+    /* pi/2 in 33 + 33 + 53 bits: fn*P1 and fn*P2 are exact for |fn| < 2^20 */
+    const double P1 = 1.57079632673412561417e+00, P2 = 6.07710050630396597660e-11, P3 = 2.02226624871116645580e-21;
+    const double fn = rint(x * INV_PIO2);
+    double r = SDRX_FMA(-fn, P1, x);
+    r = SDRX_FMA(-fn, P2, r);
+    r = SDRX_FMA(-fn, P3, r);
+    const int k = (int)fn & 3; /* |fn| < 2^20 whenever the result is used */
+    const double sr = sdrx_ksin(r);
+    const double cr = sdrx_kcos(r);
+    const double ss = (k & 1) ? cr : sr; /* k = 0: s =  sr, c =  cr */
+    const double cc = (k & 1) ? sr : cr; /* k = 1: s =  cr, c = -sr */
+    *s = (k & 2) ? -ss : ss;             /* k = 2: s = -sr, c = -cr */
+    *c = ((k + 1) & 2) ? -cc : cc;       /* k = 3: s = -cr, c =  sr */
+    return !(__builtin_fabs(x) <= 1.5e6);
+}
+
+/* |x| > 1.5e6, infinite or NaN */
+SDRX_HD void sdrx_sincos_rare(double x, double *s, double *c)
+{
+    /* 2^20 * 2*pi split in three pieces with 26 trailing zero bits each (coarse stage for huge |x|) */
+    const double M1 = 6588397.0, M2 = 0.31666114181280136 /* 0x1.4442d18p-2 */, M3 = 2.56827048412547e-10;
+    if (!(__builtin_fabs(x) < 1.0e300)) { /* inf / nan / absurd */
+        *s = x - x;
+        *c = x - x;
+        return;
+    }
+    const double q = rint(x * 1.5178198155583891e-07); /* 1/(2^20*2pi) */
+    (void)sdrx_sincos_core(((x - q * M1) - q * M2) - q * M3, s, c);
+}
 
 /* s = sin(x), c = cos(x).  Same bits on every IEEE-754 target. */
 SDRX_HD void sdrx_sincos(double x, double *s, double *c)
 {
-    const double INV_PIO2 = 6.36619772367581382433e-01;
-    /* pi/2 split in 33-bit pieces: fn*P1 and fn*P2 are exact for |fn| < 2^20 */
-    const double P1 = 1.57079632673412561417e+00, P2 = 6.07710050630396597660e-11,
-                 P3 = 2.02226624871116645580e-21, P3T = 8.47842766036889956997e-32;
-    /* 2^20 * 2*pi split in three pieces with 26 trailing zero bits each (coarse stage for huge |x|) */
-    const double M1 = 6588397.0, M2 = 0.31666114181280136 /* 0x1.4442d18p-2 */, M3 = 2.56827048412547e-10;
-    /* The common path (|x| <= 1.5e6, finite) is straight-line: inside the PSK carrier loop this is the longest part of
-     * a serial chain.  Huge, infinite and NaN arguments (a loop that has run away) are handled under two wave-uniform
-     * tests that cost one scalar branch each when no lane needs them. */
-    const double x0 = x;
-    const double ax = x < 0.0 ? -x : x;
-    const int rare = !(ax <= 1.5e6); /* huge, inf or nan */
-    int bad = 0;
-    if (SDRX_ANY_LANE(rare)) {
-        bad = !(ax < 1.0e300); /* inf / nan / absurd */
-        const int big = ax > 1.5e6;
-        const double q = rint(x * 1.5178198155583891e-07); /* 1/(2^20*2pi) */
-        const double xr = ((x - q * M1) - q * M2) - q * M3;
-        x = big ? xr : x;
-    }
-    const double fn = rint(x * INV_PIO2);
-    double r = ((x - fn * P1) - fn * P2) - fn * P3;
-    r = r - fn * P3T;
-    int k = (int)fn & 3; /* |fn| < 2^23 whenever the result is used */
-    const double sr = sdrx_ksin(r);
-    const double cr = sdrx_kcos(r);
-    if (SDRX_ANY_LANE(bad)) k = bad ? 0 : k;
-    const double ss = (k & 1) ? cr : sr; /* k = 0: s =  sr, c =  cr */
-    const double cc = (k & 1) ? sr : cr; /* k = 1: s =  cr, c = -sr */
-    double sv = (k & 2) ? -ss : ss; /* k = 2: s = -sr, c = -cr */
-    double cv = ((k + 1) & 2) ? -cc : cc; /* k = 3: s = -cr, c =  sr */
-    if (SDRX_ANY_LANE(bad)) {
-        sv = bad ? x0 - x0 : sv;
-        cv = bad ? x0 - x0 : cv;
-    }
-    *s = sv;
-    *c = cv;
+    if (sdrx_sincos_core(x, s, c)) sdrx_sincos_rare(x, s, c);
 }
 
 /* ---- atan / atan2 ------------------------------------------------------- */

@@ -21,7 +21,9 @@ src = os.path.join(root, "..", "gpurun_out", "prof", tag)
 
 def counters(sub):
     acc = collections.defaultdict(list)
-    path = os.path.join(src, sub, f"{wl}_counter_collection.csv")
+    path = os.path.join(src, f"{sub}_{wl}", f"{wl}_counter_collection.csv")
+    if not os.path.exists(path):  # round-1 layout: one directory per pass, shared by the workloads
+        path = os.path.join(src, sub, f"{wl}_counter_collection.csv")
     if not os.path.exists(path):
         return {}
     for r in csv.DictReader(open(path)):
@@ -31,7 +33,10 @@ def counters(sub):
 
 
 stats = []
-for r in csv.DictReader(open(os.path.join(src, "kt", f"{wl}_kernel_stats.csv"))):
+kt = os.path.join(src, f"kt_{wl}", f"{wl}_kernel_stats.csv")
+if not os.path.exists(kt):
+    kt = os.path.join(src, "kt", f"{wl}_kernel_stats.csv")
+for r in csv.DictReader(open(kt)):
     stats.append(r)
 with open(os.path.join(root, f"{tag}_{wl}_kernel_stats.csv"), "w") as f:
     w = csv.writer(f)
@@ -52,7 +57,7 @@ out = {
     "hbm_bytes_per_launch": fetch_b + write_b,
     "corrections": "FETCH_SIZE x2 (gfx950 wide-read half-count), KiB -> bytes; WRITE_SIZE KiB -> bytes",
 }
-bl = os.path.join(src, "bench_line.json")
+bl = os.path.join(src, f"bench_line_{wl}.json")  # one per workload (round 1 shared one file: r01_cfg1 carried cfg3's line)
 if os.path.exists(bl):
     try:
         out["bench_line_under_profiler"] = json.loads(open(bl).read())

@@ -79,8 +79,10 @@ Tuning &tuning()
         x.fir_nt = env_int("SDRX_FIR_NT", d.fir_nt);
         x.fir_lds_soft_kb = env_int("SDRX_FIR_LDS_SOFT_KB", d.fir_lds_soft_kb);
         x.fir_ct = env_int("SDRX_FIR_CT", d.fir_ct);
+        x.fir_fill = env_int("SDRX_FIR_FILL", d.fir_fill);
         x.psk_split = env_int("SDRX_PSK_SPLIT", d.psk_split);
         x.psk_overlap = env_int("SDRX_PSK_OVERLAP", d.psk_overlap);
+        x.psk_pieces = env_int("SDRX_PSK_PIECES", d.psk_pieces);
         x.iir_cw = env_int("SDRX_IIR_CW", d.iir_cw);
         return x;
     }();
@@ -177,8 +179,10 @@ extern "C" int sdrx_tune(const char *name, const char *value)
     else if (strcmp(name, "SDRX_FIR_NT") == 0) t.fir_nt = dflt ? d.fir_nt : v;
     else if (strcmp(name, "SDRX_FIR_LDS_SOFT_KB") == 0) t.fir_lds_soft_kb = dflt ? d.fir_lds_soft_kb : v;
     else if (strcmp(name, "SDRX_FIR_CT") == 0) t.fir_ct = dflt ? d.fir_ct : v;
+    else if (strcmp(name, "SDRX_FIR_FILL") == 0) t.fir_fill = dflt ? d.fir_fill : v;
     else if (strcmp(name, "SDRX_PSK_SPLIT") == 0) t.psk_split = dflt ? d.psk_split : v;
     else if (strcmp(name, "SDRX_PSK_OVERLAP") == 0) t.psk_overlap = dflt ? d.psk_overlap : v;
+    else if (strcmp(name, "SDRX_PSK_PIECES") == 0) t.psk_pieces = dflt ? d.psk_pieces : v;
     else if (strcmp(name, "SDRX_IIR_CW") == 0) t.iir_cw = dflt ? d.iir_cw : v;
     else {
         set_error("sdrx_tune: unknown switch %s", name);
@@ -401,10 +405,10 @@ static int mf_launch(const double *iq, size_t n, size_t nchan, size_t in_pitch, 
 // its history is the samples in front of it: sdrx_fir_job.n_before) runs beside the loops of piece k (a side stream
 // of the library, ordered by events); loop state carries from piece to piece exactly as from call to call.  Same
 // kernels, same arithmetic, same order per channel: results are bit-identical to the one-stream form.
-static const int PSK_PIECES = 4;
+static const int PSK_PIECES_MAX = 16;
 struct PskPipe {
     hipStream_t side = nullptr;
-    hipEvent_t ev[PSK_PIECES + 1] = {};
+    hipEvent_t ev[PSK_PIECES_MAX + 1] = {};
     bool ready = false;
 };
 static std::mutex g_pipe_mu;
@@ -417,7 +421,7 @@ static PskPipe *psk_pipe_locked() // g_pipe_mu held; created on the first use on
     PskPipe &p = g_pipe[dev];
     if (!p.ready) {
         bool ok = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) == hipSuccess;
-        for (int k = 0; ok && k <= PSK_PIECES; k++) ok = hipEventCreateWithFlags(&p.ev[k], hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; ok && k <= PSK_PIECES_MAX; k++) ok = hipEventCreateWithFlags(&p.ev[k], hipEventDisableTiming) == hipSuccess;
         if (!ok) return nullptr;
         p.ready = true;
     }
@@ -434,11 +438,13 @@ static int psk_demod_common(int kind, const double *iq, size_t n, size_t nchan, 
     double *dst = (double *)((unsigned char *)zst + align256(nchan * MF_STATE * sizeof(double)));
     double *carry = (double *)((unsigned char *)dst + align256(nchan * MF_STATE * sizeof(double)));
     KernelChain kc;
-    const int want = tuning().psk_overlap;
+    const Tuning &tune = tuning();
+    const int want = tune.psk_overlap;
     // Pays only where the loops dominate (few channels, long blocks): there the matched filter hides behind them
     // (2^12 channels x 2^14 samples: 1.63 -> 1.51 ms).  Where the two take similar time (2^14 x 2^12) the loop waves,
     // sharing their SIMDs with matched-filter waves, slow down by as much as the overlap saves (0.74 -> 0.89 ms;
     // profiles/r02_cfg3_overlap_trace.json), s_setprio and a high-priority queue notwithstanding: off by default there.
+    // Giving each stage CUs of its own (CU-masked queues) is worse still: profiles/r02_cfg3_cumask.json.
     const bool overlap = may_overlap && want != 0 && m >= 512 && (want > 0 || (nchan <= (1u << 12) && m >= 2048));
     if (!overlap) {
         int rc = mf_launch(iq, n, nchan, in_pitch, mf, m, zst, dst, s, offs_buf, offs_cap);
@@ -450,27 +456,29 @@ static int psk_demod_common(int kind, const double *iq, size_t n, size_t nchan, 
     std::lock_guard<std::mutex> lk(g_pipe_mu); // one call's events at a time
     PskPipe *pp = psk_pipe_locked();
     if (!pp) {
-        set_error("sdrx_psk_demod_dev: side stream / events could not be created");
+        set_error("sdrx_psk_demod_dev: side streams / events could not be created");
         return SDRX_EHIP;
     }
-    const size_t m_piece = (((m + PSK_PIECES - 1) / PSK_PIECES) + 15) & ~(size_t)15; // whole ring blocks, even: /2 keeps 0, 2, ...
+    const int pieces = tune.psk_pieces < 2 ? 2 : (tune.psk_pieces > PSK_PIECES_MAX ? PSK_PIECES_MAX : tune.psk_pieces);
+    const size_t m_piece = (((m + pieces - 1) / pieces) + 15) & ~(size_t)15; // whole ring blocks, even: /2 keeps 0, 2, ...
+    hipStream_t s_mf = s, s_lp = pp->side;
     int k = 0;
     for (size_t m0 = 0; m0 < m; m0 += m_piece, k++) {
         const bool last = m0 + m_piece >= m;
         const size_t mk = last ? m - m0 : m_piece;
-        int rc = mf_launch(iq + 2 * 4 * m0, last ? n - 4 * m0 : 4 * mk, nchan, in_pitch, mf + 2 * m0, m, zst, dst, s, offs_buf,
+        int rc = mf_launch(iq + 2 * 4 * m0, last ? n - 4 * m0 : 4 * mk, nchan, in_pitch, mf + 2 * m0, m, zst, dst, s_mf, offs_buf,
                            offs_cap, 4 * m0, mk);
         if (rc) return rc;
-        SDRX_HIP(hipEventRecord(pp->ev[k], s));
-        SDRX_HIP(hipStreamWaitEvent(pp->side, pp->ev[k], 0));
-        rc = launch_psk_loops(kind, mf + 2 * m0, mk, nchan, m, states, out + m0 / 2, out_pitch, 1, 1, pp->side, carry,
+        SDRX_HIP(hipEventRecord(pp->ev[k], s_mf));
+        SDRX_HIP(hipStreamWaitEvent(s_lp, pp->ev[k], 0));
+        rc = launch_psk_loops(kind, mf + 2 * m0, mk, nchan, m, states, out + m0 / 2, out_pitch, 1, 1, s_lp, carry,
                               (m0 ? 1 : 0) | (last ? 0 : 2));
         if (rc) return rc;
     }
-    int rc = launch_psk_ambiguity(kind, out, (m + 1) / 2, nchan, out_pitch, states, pp->side);
+    int rc = launch_psk_ambiguity(kind, out, (m + 1) / 2, nchan, out_pitch, states, s_lp);
     if (rc) return rc;
-    SDRX_HIP(hipEventRecord(pp->ev[PSK_PIECES], pp->side));
-    SDRX_HIP(hipStreamWaitEvent(s, pp->ev[PSK_PIECES], 0)); // everything behind the call on the caller's stream sees its results
+    SDRX_HIP(hipEventRecord(pp->ev[PSK_PIECES_MAX], s_lp));
+    SDRX_HIP(hipStreamWaitEvent(s, pp->ev[PSK_PIECES_MAX], 0)); // everything behind the call on the caller's stream sees its results
     return SDRX_OK;
 }
 

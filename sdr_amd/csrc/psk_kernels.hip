@@ -127,12 +127,19 @@ __device__ __forceinline__ void timing_step(TimingState &t, double &re, double &
 }
 
 // One sample through phase_shift_correction + the output lookup; returns the decision.
-template <int KIND> __device__ __forceinline__ int phase_step(PhaseState &p, double re, double im)
+// SPECULATE: only sincos's straight-line common case runs and `rare` collects its "argument out of range" flag: the
+// caller repeats the block without SPECULATE if any lane raised it (sdrx_math.h: sdrx_sincos_core).
+template <int KIND, bool SPECULATE = false>
+__device__ __forceinline__ int phase_step(PhaseState &p, double re, double im, bool *rare = nullptr)
 {
     const double PK1 = 0.0620001240002480, PK2 = 0.000992001984003968; // BPSK.cpp:424-432
     double sn, cs;
+    auto sincos_of = [&](double a) {
+        if constexpr (SPECULATE) *rare |= sdrx_sincos_core(a, &sn, &cs) != 0;
+        else sdrx_sincos(a, &sn, &cs);
+    };
     if constexpr (KIND == SDRX_BPSK) { // BPSK.cpp:399-411
-        sdrx_sincos(p.dds_delay + p.temp, &sn, &cs);
+        sincos_of(p.dds_delay + p.temp);
         p.dds_delay = p.dds_delay + p.temp;
         p.tr = re * cs - im * sn;
         p.ti = im * cs + re * sn;
@@ -146,7 +153,7 @@ template <int KIND> __device__ __forceinline__ int phase_step(PhaseState &p, dou
         p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
         p.plf_x = val;
         p.plf_y = p.temp;
-        sdrx_sincos(p.dds_delay + p.temp, &sn, &cs);
+        sincos_of(p.dds_delay + p.temp);
         p.dds_delay = p.dds_delay + p.temp;
         p.tr = re * cs - im * sn;
         p.ti = im * cs + re * sn;
@@ -292,12 +299,27 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
             }
         } else if (j >= 1) {
             const size_t i0 = (j - 1) * SPLIT_KB;
+            // the block on sincos's common case alone; if any lane's argument was outside it (a loop that has run
+            // away: never in normal operation) the block is repeated from the saved state through the full function,
+            // which returns the same values for every lane that was inside
+            const PhaseState p0 = p;
+            bool rare = false;
 #pragma unroll
             for (int k = 0; k < SPLIT_KB; k++) {
                 const double2 v = ring[(j - 1) & 1][k][lane];
                 if (i0 + k < m) {
-                    const int decision = phase_step<KIND>(p, v.x, v.y);
+                    const int decision = phase_step<KIND, true>(p, v.x, v.y, &rare);
                     if ((k & 1) == 0 && active) d[(i0 + k) >> 1] = (uint8_t)decision; // SPLIT_KB is even: parity of k
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+                p = p0;
+                for (int k = 0; k < SPLIT_KB; k++) {
+                    const double2 v = ring[(j - 1) & 1][k][lane];
+                    if (i0 + k < m) {
+                        const int decision = phase_step<KIND>(p, v.x, v.y);
+                        if ((k & 1) == 0 && active) d[(i0 + k) >> 1] = (uint8_t)decision;
+                    }
                 }
             }
         }

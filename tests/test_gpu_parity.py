@@ -1590,3 +1590,42 @@ def test_fir_job_n_before_tiles_a_stream_in_time():
     j = ch2._job(_lib.IQ_INTERLEAVED, x, None, 100, n, g0, g1, n_out, False, 0)
     j.n_before = 10  # shorter than the filter's history: refused
     assert Lx.sdrx_fir_dev(C.byref(j)) == -1
+
+
+def test_psk_carrier_loop_outside_the_common_range_of_sincos(tune):
+    """The split kernel runs each 16-sample block of the carrier loop on sincos's straight-line common case
+    (|phase| <= 1.5e6) and repeats the block through the full function if any lane left it.  Channels that start
+    near the limit (and cross it inside a block), far beyond it, at an absurd phase, and one fed an infinite sample
+    give the oracle's decisions and loop state bit for bit (NaNs in the same places), in both kernel forms, next to
+    ordinary channels in the same wave."""
+    n = 4096
+    starts = [0.0, 1.4999999e6, -1.49999995e6, 3.0e7, -2.5e9, 1.0e301, 0.0, 0.0]
+    nchan = len(starts)
+    for kind, lk in ((O.QPSK, _lib.QPSK), (O.BPSK, _lib.BPSK)):
+        iqs = [np.asarray(psk_test_signal(kind, n // 8, seed=900 + c, phase_deg=30.0 * c, snr_db=12.0, timing_offset=c % 4),
+                          dtype=np.float64).copy() for c in range(nchan)]
+        iqs[6][2 * 2000] = np.inf  # one infinite I sample: the loops run on NaN from there on
+        x = torch.tensor(np.stack([z.reshape(-1, 2) for z in iqs]), device="cuda")
+        sts = []
+        wants = []
+        for c in range(nchan):
+            st = O.psk_new(kind, math_mode=O.MATH_SHARED)
+            st.dds_delay = starts[c]
+            wants.append([O.psk_demodulate(st, iqs[c]) for _ in range(2)])
+            sts.append(st)
+        for force in ("1", "0"):
+            tune("SDRX_PSK_SPLIT", force)
+            b = device.PskBank(lk, nchan, n)
+            rows = b.states.cpu().numpy().copy()
+            rows[:, : 8 * 24].view(np.float64)[:, 21] = starts
+            b.states.copy_(torch.tensor(rows))
+            for blk in range(2):
+                o = torch.zeros(nchan, b.n_dec, dtype=torch.uint8, device="cuda")
+                b.demod(x, o)
+                got = o.cpu().numpy()
+                for c in range(nchan):
+                    assert np.array_equal(got[c][: wants[c][blk].size], wants[c][blk]), (kind, force, blk, c)
+            hs = b.states.cpu().numpy()
+            for c in range(nchan):
+                assert np.array_equal(hs[c][: 8 * 24].view(np.float64), sts[c].loop_state(), equal_nan=True), (kind, force, c)
+        assert np.isnan(sts[6].loop_state()).any() and not np.isnan(sts[7].loop_state()).any()
