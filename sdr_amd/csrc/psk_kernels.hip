@@ -427,12 +427,62 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
     if (tid < 4) s_cc[tid] = st->cc[tid];
     if (tid == 0) s_nh = 0;
     __syncthreads();
+    // One-wave form: a position's U decisions are compared four bytes at a time.  A 32-bit word of the staged row at
+    // any byte offset is two aligned LDS reads joined by v_alignbyte; the unique word's four rotations are packed into
+    // words once per channel (uwq[q] = word q of all four).  QPSK's compare is an if / else-if chain per symbol
+    // (QPSK.cpp:432-443: a symbol equal to an earlier rotation's entry never counts for a later one), which equals
+    // "all U symbols match rotation k" whenever the four rows differ pairwise at every index -- always so for rows
+    // built from the LUT rotations; a unique word with out-of-range entries leaves equal rows and takes the
+    // symbol-by-symbol loop below.
+    __shared__ uint4 uwq[16];
+    bool fast = false;
+    if constexpr (STAGED) {
+        bool clash = false;
+        if ((int)tid < U && kind != SDRX_BPSK)
+            for (int k = 0; k < 4; k++)
+                for (int l = k + 1; l < 4; l++) clash = clash || uwc[k][tid] == uwc[l][tid];
+        fast = __builtin_amdgcn_ballot_w64(clash) == 0; // NT == 64: the workgroup is one wave
+        if (fast && tid < 16) {
+            unsigned w[4] = {0, 0, 0, 0};
+            for (int b = 0; b < 4; b++) {
+                const int j = 4 * (int)tid + b;
+                if (j < U)
+                    for (int k = 0; k < 4; k++) w[k] |= (unsigned)uwc[k][j] << (8 * b);
+            }
+            uwq[tid] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __syncthreads();
+    }
+    int cc0 = s_cc[0], cc1 = s_cc[1], cc2 = s_cc[2], cc3 = s_cc[3], nh = 0; // one-wave form: the counters as wave-uniform values
     if (m >= (size_t)U) {
         const size_t npos = m - (size_t)U; // i < num_of_points - UW_SIZE
         for (size_t base = 0; base < npos; base += NT) {
             const size_t i = base + tid;
             int code = -1;
-            if (i < npos) {
+            if (STAGED && fast) {
+                const unsigned *D = (const unsigned *)sd;
+                const unsigned ic = i < npos ? (unsigned)i : 0u;
+                const unsigned a = ic >> 2, sh = ic & 3u;
+                unsigned lo = D[a];
+                unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                const int nq = (U + 3) >> 2;
+                for (int q = 0; q < nq; q++) {
+                    const unsigned hi = D[a + q + 1]; // at most byte m + 6 of sd[2048 + 16]
+                    unsigned w = __builtin_amdgcn_alignbyte(hi, lo, sh); // row bytes ic + 4q .. ic + 4q + 3
+                    lo = hi;
+                    const int rem = U - 4 * q;
+                    if (rem < 4) w &= (1u << (8 * rem)) - 1u;
+                    const uint4 u = uwq[q];
+                    d0 |= w ^ u.x;
+                    d1 |= w ^ u.y;
+                    d2 |= w ^ u.z;
+                    d3 |= w ^ u.w;
+                }
+                if (i < npos) {
+                    if (kind == SDRX_BPSK) code = d0 == 0 ? 0 : (d1 == 0 ? 2 : -1);
+                    else code = d0 == 0 ? 0 : (d1 == 0 ? 1 : (d2 == 0 ? 2 : (d3 == 0 ? 3 : -1)));
+                }
+            } else if (i < npos) {
                 if (kind == SDRX_BPSK) {
                     bool m0 = true, m180 = true;
                     for (int j = 0; j < U && (m0 || m180); j++) {
@@ -453,6 +503,27 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
                     code = cnt0 == U ? 0 : (cnt1 == U ? 1 : (cnt2 == U ? 2 : (cnt3 == U ? 3 : -1)));
                 }
             }
+            if constexpr (STAGED) {
+                // one wave: the chunk's hits as a ballot mask, folded in stream order by wave-uniform (scalar) code
+                unsigned long long hm = __builtin_amdgcn_ballot_w64(code >= 0);
+                while (hm) {
+                    const int t = __builtin_ctzll(hm);
+                    hm &= hm - 1;
+                    const int cd = __builtin_amdgcn_readlane(code, t);
+                    if (kind == SDRX_BPSK) {
+                        if (cd == 0) { if (--cc0 <= 0) cc0 = 0; }   // --cc: BPSK.cpp:468
+                        else { if (++cc0 >= 10) cc0 = 10; }          // ++cc: BPSK.cpp:473
+                    } else {                                         // QPSK.cpp:446-477
+                        if (cd == 0) { if (++cc0 >= 10) cc0 = 10; } else { if (--cc0 <= 0) cc0 = 0; }
+                        if (cd == 1) { if (++cc1 >= 10) cc1 = 10; } else { if (--cc1 <= 0) cc1 = 0; }
+                        if (cd == 2) { if (++cc2 >= 10) cc2 = 10; } else { if (--cc2 <= 0) cc2 = 0; }
+                        if (cd == 3) { if (++cc3 >= 10) cc3 = 10; } else { if (--cc3 <= 0) cc3 = 0; }
+                    }
+                    if (hits && (size_t)nh < max_hits && tid == 0)
+                        hits[c * max_hits + nh] = ((unsigned long long)(base + t) << 3) | (unsigned long long)cd;
+                    nh++;
+                }
+            } else {
             ev[tid] = (signed char)code;
             const int any = __syncthreads_or(code >= 0);
             if (any && tid == 0) {
@@ -474,7 +545,11 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
                 }
             }
             __syncthreads();
+            }
         }
+    }
+    if constexpr (STAGED) {
+        if (tid == 0) { s_cc[0] = cc0; s_cc[1] = cc1; s_cc[2] = cc2; s_cc[3] = cc3; s_nh = nh; }
     }
     if (tid == 0) {
         int lut = -1;
@@ -492,6 +567,21 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
     __syncthreads();
     const int lut = s_lut;
     if (lut < 0) return;
+    if constexpr (STAGED) {
+        if ((((size_t)d) & 3) == 0) { // four decisions per lane from the staged row; the maps on packed bytes
+            for (size_t w = tid; w < (m + 3) / 4; w += NT) {
+                const unsigned v = *(const unsigned *)(sd + 4 * w), b = 0x01010101u;
+                unsigned o;
+                if (kind == SDRX_BPSK) o = v ^ b;
+                else if (lut == 1) o = ((~v & b) << 1) | ((v >> 1) & b); // {2,0,3,1}: out1 = !in0, out0 = in1
+                else if (lut == 2) o = 3u * b - (v & (3u * b));          // {3,2,1,0}
+                else o = ((v & b) << 1) | ((~v >> 1) & b);               // {1,3,0,2}: out1 = in0, out0 = !in1
+                if (4 * w + 4 <= m) *(unsigned *)(d + 4 * w) = o;
+                else for (size_t k = 4 * w; k < m; k++) d[k] = (uint8_t)(o >> (8 * (k - 4 * w)));
+            }
+            return;
+        }
+    }
     for (size_t i = tid; i < m; i += NT) {
         const unsigned v = d[i];
         unsigned o;

@@ -1629,3 +1629,52 @@ def test_psk_carrier_loop_outside_the_common_range_of_sincos(tune):
             for c in range(nchan):
                 assert np.array_equal(hs[c][: 8 * 24].view(np.float64), sts[c].loop_state(), equal_nan=True), (kind, force, c)
         assert np.isnan(sts[6].loop_state()).any() and not np.isnan(sts[7].loop_state()).any()
+
+
+@pytest.mark.parametrize("kind,lk", [(O.BPSK, _lib.BPSK), (O.QPSK, _lib.QPSK)])
+def test_psk_ambiguity_stage_unique_word_lengths_and_rows(kind, lk):
+    """sdrx_psk_ambiguity_dev alone, on decision rows with planted unique words in every rotation (some overlapping,
+    some cut by the end of the row): unique-word lengths that are and are not multiples of four (the one-wave form
+    compares four symbols per operation), 0 and 64, row lengths on both sides of the one-wave / 256-thread switch, a
+    QPSK unique word with out-of-range entries (its four rows coincide there: the symbol-by-symbol loop), two calls in
+    a row (confidence counters carried).  Decisions, counters and hit count equal the oracle's."""
+    Lx = _lib.lib()
+    rng = np.random.default_rng(77 + kind)
+    nsym = 2 if kind == O.BPSK else 4
+    cases = [(8, None), (13, None), (16, None), (31, None), (64, None), (0, None), (1, None)]
+    if kind == O.QPSK:
+        bad = np.array(rng.integers(0, 4, 64), dtype=np.float64)
+        bad[60] = 7.0  # not a symbol: QPSK.cpp:103 leaves this index at 0 in all four rows
+        cases.append((16, bad))
+    for U, uw in cases:
+        for m in (255, 256, 300, 301, 2048, 2049, 5000):
+            nchan = 5
+            if kind == O.BPSK:
+                word = int(rng.integers(0, 2 ** 63)) if uw is None else uw
+                sts = [O.psk_new(kind, uw=word, uw_len=U, math_mode=O.MATH_SHARED) for _ in range(nchan)]
+                b = device.PskBank(lk, nchan, 8 * m, unique_word=word, uw_len=U)
+            else:
+                word = np.array(rng.integers(0, 4, 64), dtype=np.float64) if uw is None else uw
+                sts = [O.psk_new(kind, uw=word, uw_len=U, math_mode=O.MATH_SHARED) for _ in range(nchan)]
+                b = device.PskBank(lk, nchan, 8 * m, unique_word=word, uw_len=U)
+            rows = [np.array([sts[0].uw[k][(U - 1 - j) if kind == O.BPSK else (63 - j)] for j in range(U)])
+                    for k in range(4 if kind == O.QPSK else 2)]
+            for call in range(2):
+                dec = rng.integers(0, nsym, (nchan, m)).astype(np.uint8)
+                for c in range(nchan):
+                    for _ in range(0 if U == 0 else 1 + 3 * c):
+                        k = int(rng.integers(0, len(rows)))
+                        pos = int(rng.integers(0, m))
+                        seg = rows[k][: max(0, min(U, m - pos))]
+                        dec[c, pos: pos + seg.size] = seg.astype(np.uint8)
+                d = torch.tensor(dec, device="cuda")
+                _lib.check(Lx.sdrx_psk_ambiguity_dev(lk, C.c_void_p(d.data_ptr()), m, nchan, m, C.c_void_p(b.states.data_ptr()), None),
+                           "ambiguity")
+                got = d.cpu().numpy()
+                hs = b.host_states()
+                for c in range(nchan):
+                    want = dec[c].astype(np.float64)
+                    nh = O.lib().orc_psk_ambiguity(C.byref(sts[c]), want, m, None, 0)
+                    assert np.array_equal(got[c], want.astype(np.uint8)), (U, m, call, c)
+                    assert list(hs[c].cc) == list(sts[c].cc), (U, m, call, c)
+                    assert hs[c].n_hits == nh, (U, m, call, c)
