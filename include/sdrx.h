@@ -80,7 +80,8 @@ const char *sdrx_last_kernel(void);
  * x[c][i<0] comes from the channel's carried history (Filter's shift register, filt.cpp:256-259).
  * State per channel (doubles): hist0[T-1] (x[-1], x[-2], ...), hist1[T-1] (second rail), pre[2].
  * state_in and state_out must be different buffers (a launch reads one and writes the other);
- * state_pitch >= 2*(T-1)+2.  Outputs never alias inputs.
+ * state_pitch >= 2*(T-1)+2.  Outputs never alias inputs.  sdrx_fir_dev only, modes 0 and 1: state_in = state_out = NULL
+ * is a one-shot call: zero history, no state kept (what decode_pulseShape does on every call, BPSK.cpp:267-268).
  */
 typedef struct sdrx_fir_job {
     int layout;               /* SDRX_REAL / SDRX_IQ_SPLIT / SDRX_IQ_INTERLEAVED / SDRX_IQ_U8 */

@@ -38,26 +38,6 @@ double am_threshold_sq()
     return thr2;
 }
 
-// ---- small device scratch cache (stage-level entry points only; the *_dev hot path never allocates)
-struct Scratch {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes)
-    {
-        if (bytes <= cap) return SDRX_OK;
-        if (p) {
-            SDRX_HIP(hipDeviceSynchronize());
-            SDRX_HIP(hipFree(p));
-            p = nullptr;
-            cap = 0;
-        }
-        size_t want = bytes + bytes / 4 + 256;
-        SDRX_HIP(hipMalloc(&p, want));
-        cap = want;
-        return SDRX_OK;
-    }
-};
-
 thread_local LastKernel t_last_kernel;
 
 static int env_int(const char *name, int dflt)
@@ -375,7 +355,8 @@ static int mf_launch(const double *iq, size_t n, size_t nchan, size_t in_pitch, 
     }
     if (n_out == (size_t)-1) n_out = n / 4; // memcpy of number_of_points/4 values: BPSK.cpp:292-293
     if (n_out == 0) return SDRX_OK;
-    if (n_before == 0) SDRX_HIP(hipMemsetAsync(zero_state, 0, nchan * MF_STATE * sizeof(double), stream));
+    (void)zero_state; // a job without state rows starts from a zero history and keeps none (BPSK.cpp:267-268 re-pads
+    (void)dummy_state; // with zeros on every call): no rows to clear before, none written after
     sdrx_fir_job j;
     memset(&j, 0, sizeof(j));
     j.layout = SDRX_IQ_INTERLEAVED;
@@ -387,8 +368,8 @@ static int mf_launch(const double *iq, size_t n, size_t nchan, size_t in_pitch, 
     j.taps = taps;
     j.num_taps = (int)MF_T;
     j.decim = 4; // decimate(.., 4): BPSK.cpp:289-290
-    j.state_in = zero_state;
-    j.state_out = dummy_state;
+    j.state_in = nullptr;
+    j.state_out = nullptr;
     j.state_pitch = MF_STATE;
     j.out0 = mf_iq;
     j.out1 = nullptr;
@@ -552,32 +533,18 @@ extern "C" int sdrx_psk_demod_noalloc_dev(int kind, const double *iq, size_t n, 
     unsigned char *base = nullptr;
     int rc = noalloc_setup(&base);
     if (rc) return rc;
-    // everything the kernels expect to start at zero is cleared by the matched-filter launch (the zero-history rows);
-    // the rest of the array keeps the last call's contents and is overwritten before it is read.  One stream, no
+    // nothing in the array has to start at zero (the matched filter takes its zero history from no rows at all): it
+    // keeps the last call's contents and every part is overwritten before it is read.  One stream, no
     // block pipeline: its side stream and events would be created on first use.
     return psk_demod_common(kind, iq, n, nchan, in_pitch, states, out, out_pitch, base + NOALLOC_OFFS_BYTES,
                             (hipStream_t)stream, (int *)base, (unsigned)NOALLOC_OFFS_INTS, false);
 }
 
-// sdrx_psk_matched_filter_dev's zero / dummy state rows: one buffer per device, grown on demand.  The lock is held
-// from the size check to the launch, and growing waits for the device before it frees, so a buffer is never freed
-// under a launch in flight (host threads of different radios may call concurrently: rtlsdr_receiver.cpp:191-194).
-static std::mutex g_mf_scratch_mu;
-static std::map<int, Scratch> g_mf_scratch;
-
 extern "C" int sdrx_psk_matched_filter_dev(const double *iq, size_t n, size_t nchan, size_t in_pitch, double *mf_iq,
                                            size_t mf_pitch, void *stream)
 {
     if (!iq || !mf_iq) return SDRX_EINVAL;
-    int dev = 0;
-    SDRX_HIP(hipGetDevice(&dev));
-    const size_t st_bytes = align256(nchan * MF_STATE * sizeof(double));
-    std::lock_guard<std::mutex> lk(g_mf_scratch_mu);
-    Scratch &sc = g_mf_scratch[dev];
-    int rc = sc.ensure(2 * st_bytes);
-    if (rc) return rc;
-    return mf_launch(iq, n, nchan, in_pitch, mf_iq, mf_pitch, (double *)sc.p, (double *)((unsigned char *)sc.p + st_bytes),
-                     (hipStream_t)stream);
+    return mf_launch(iq, n, nchan, in_pitch, mf_iq, mf_pitch, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int sdrx_psk_loops_dev(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch,

@@ -12,6 +12,7 @@
 // in registers and exactly the reference's operation order (no FMA contraction); throughput comes
 // from the number of independent channels.  cos/sin are include/sdrx_math.h on both sides.
 #include "sdrx_internal.h"
+#include <type_traits>
 
 #include <cstdlib>
 #include <mutex>
@@ -276,6 +277,30 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
                      st->g1, st->g2, st->g3, st->g4, st->lf_x, st->lf_y};
     PhaseState p = {st->dds_delay, st->plf_x, st->plf_y, 0.0, 0.0, 0.0};
     if (piece & PIECE_NOT_FIRST) { p.tr = carry[4 * c]; p.ti = carry[4 * c + 1]; p.temp = carry[4 * c + 2]; }
+    // A block that lies wholly inside the call (all but the last) runs without a per-sample test: one straight-line
+    // run of SPLIT_KB steps, so the delay lines are renamed instead of moved and the signs the Gardner detector takes
+    // of older samples are the ones already computed for them.
+    auto timing_block = [&](auto full, const double2 (&cur)[SPLIT_KB], size_t j) {
+#pragma unroll
+        for (int k = 0; k < SPLIT_KB; k++) {
+            double re = cur[k].x, im = cur[k].y;
+            if (decltype(full)::value || j * SPLIT_KB + k < m) timing_step(t, re, im); // uniform: m is the same for all lanes
+            ring[j & 1][k][lane] = make_double2(re, im);
+        }
+    };
+    auto carrier_block = [&](auto full, auto speculate, size_t jb, bool &rare) {
+        const size_t i0 = jb * SPLIT_KB;
+#pragma unroll
+        for (int k = 0; k < SPLIT_KB; k++) {
+            const double2 v = ring[jb & 1][k][lane];
+            if (decltype(full)::value || i0 + k < m) {
+                const int decision = phase_step<KIND, decltype(speculate)::value>(p, v.x, v.y, &rare);
+                if ((k & 1) == 0 && active) d[(i0 + k) >> 1] = (uint8_t)decision; // SPLIT_KB is even: parity of k
+            }
+        }
+    };
+    typedef std::integral_constant<bool, true> yes_t;
+    typedef std::integral_constant<bool, false> no_t;
     double2 nxt[SPLIT_KB];
     if (role == 0) {
 #pragma unroll
@@ -288,39 +313,27 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
 #pragma unroll
                 for (int k = 0; k < SPLIT_KB; k++) cur[k] = nxt[k];
                 const size_t nb = (j + 1) * SPLIT_KB; // the next block's samples land during this block's arithmetic
+                if (nb + SPLIT_KB <= m) {
 #pragma unroll
-                for (int k = 0; k < SPLIT_KB; k++) nxt[k] = (nb + k < m) ? x[nb + k] : make_double2(0.0, 0.0);
+                    for (int k = 0; k < SPLIT_KB; k++) nxt[k] = x[nb + k];
+                } else {
 #pragma unroll
-                for (int k = 0; k < SPLIT_KB; k++) {
-                    double re = cur[k].x, im = cur[k].y;
-                    if (j * SPLIT_KB + k < m) timing_step(t, re, im); // uniform: m is the same for all lanes
-                    ring[j & 1][k][lane] = make_double2(re, im);
+                    for (int k = 0; k < SPLIT_KB; k++) nxt[k] = (nb + k < m) ? x[nb + k] : make_double2(0.0, 0.0);
                 }
+                if (nb <= m) timing_block(yes_t(), cur, j);
+                else timing_block(no_t(), cur, j);
             }
         } else if (j >= 1) {
-            const size_t i0 = (j - 1) * SPLIT_KB;
             // the block on sincos's common case alone; if any lane's argument was outside it (a loop that has run
             // away: never in normal operation) the block is repeated from the saved state through the full function,
             // which returns the same values for every lane that was inside
             const PhaseState p0 = p;
             bool rare = false;
-#pragma unroll
-            for (int k = 0; k < SPLIT_KB; k++) {
-                const double2 v = ring[(j - 1) & 1][k][lane];
-                if (i0 + k < m) {
-                    const int decision = phase_step<KIND, true>(p, v.x, v.y, &rare);
-                    if ((k & 1) == 0 && active) d[(i0 + k) >> 1] = (uint8_t)decision; // SPLIT_KB is even: parity of k
-                }
-            }
+            if (j * SPLIT_KB <= m) carrier_block(yes_t(), yes_t(), j - 1, rare);
+            else carrier_block(no_t(), yes_t(), j - 1, rare);
             if (__builtin_amdgcn_ballot_w64(rare) != 0) {
                 p = p0;
-                for (int k = 0; k < SPLIT_KB; k++) {
-                    const double2 v = ring[(j - 1) & 1][k][lane];
-                    if (i0 + k < m) {
-                        const int decision = phase_step<KIND>(p, v.x, v.y);
-                        if ((k & 1) == 0 && active) d[(i0 + k) >> 1] = (uint8_t)decision;
-                    }
-                }
+                carrier_block(no_t(), no_t(), j - 1, rare);
             }
         }
         __syncthreads();

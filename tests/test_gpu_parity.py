@@ -1678,3 +1678,32 @@ def test_psk_ambiguity_stage_unique_word_lengths_and_rows(kind, lk):
                     assert np.array_equal(got[c], want.astype(np.uint8)), (U, m, call, c)
                     assert list(hs[c].cc) == list(sts[c].cc), (U, m, call, c)
                     assert hs[c].n_hits == nh, (U, m, call, c)
+
+
+def test_fir_job_without_state_rows_is_a_one_shot_call():
+    """state_in = state_out = NULL: zero history, nothing carried -- the same outputs as a call on zeroed state rows,
+    for the workgroup-tile and the systolic kernel, exact and fma modes; refused for the AM / discriminator chains
+    and for fast mode 2."""
+    Lx = _lib.lib()
+    rng = np.random.default_rng(5)
+    for T, D, nchan, n in ((129, 4, 3, 5000), (64, 10, 2, 70000), (64, 1, 2, 3000), (7, 3, 1, 100)):
+        taps = rng.normal(0, 1, T)
+        x = torch.tensor(rng.normal(0, 50, (nchan, n, 2)), device="cuda")
+        n_out = (n + D - 1) // D
+        for fma in (0, 1):
+            ch = device.FirChain(taps, nchan, D)
+            w0, w1 = (torch.zeros(nchan, n_out, dtype=torch.float64, device="cuda") for _ in range(2))
+            ch.fir(x, w0, w1, fast_fma=fma)
+            g0, g1 = (torch.full((nchan, n_out), 7.0, dtype=torch.float64, device="cuda") for _ in range(2))
+            j = ch._job(_lib.IQ_INTERLEAVED, x, None, n, n, g0, g1, n_out, fma, 0)
+            j.state_in = None
+            j.state_out = None
+            _lib.check(Lx.sdrx_fir_dev(C.byref(j)), "stateless")
+            torch.cuda.synchronize()
+            assert torch.equal(g0, w0) and torch.equal(g1, w1), (T, D, fma)
+    j.fast_fma = 2
+    assert Lx.sdrx_fir_dev(C.byref(j)) == -1
+    j.fast_fma = 0
+    assert Lx.sdrx_fir_fmdisc_dev(C.byref(j)) == -1
+    j.state_in = C.c_void_p(ch.state[0].data_ptr())
+    assert Lx.sdrx_fir_dev(C.byref(j)) == -1  # one of the two rows only
