@@ -336,6 +336,11 @@ __global__ void __launch_bounds__(256) fsk_corr_wave_kernel(const double *__rest
     if (bit0 + lane < nbits) out[bit0 + lane] = (op1 > op2) ? 1 : 0; // FM.h:139 (repaired)
 }
 
+// Measured and left as is (round 2, profiles/r02_fsk_study.json): windows that are not a multiple of the 128-byte line
+// (ds = 100) make every line the target of two consecutive chunks, FETCH_SIZE = 1.52 x the input, 0.62 of the HBM peak
+// against 0.76-0.79 for ds = 16 / 64 / 128.  A form that loads aligned blocks into a two-block LDS ring per bit (every
+// line fetched once, FETCH = 1.0-1.16 x) was bit-identical but needs twice the LDS per wave: 8 instead of 16 waves per
+// CU, and its dependent add chains no longer hide: 0.51 (ds = 100), 0.56 (ds = 128).  Removed.
 int launch_fm_demod(const double *re, const double *w1, const double *w2, uint8_t *out, size_t n, size_t ds,
                     hipStream_t s)
 {
