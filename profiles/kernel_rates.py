@@ -126,4 +126,37 @@ for name, fn, bytes_per in (("iir dc_block", lambda: device.iir(device.IIR_DC_BL
     tot = nchan * n
     rows.append({"kernel": name + " (16384 rows x 2^13)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
                  "algorithmic_GBps": bytes_per * tot / t / 1e9, "frac_of_8TBps": bytes_per * tot / t / 1e9 / PEAK})
+del x, z
+# round 2: the modulators as device kernels (output-bound: 8 B written per output sample), the PSK stages of cfg3
+nchan, nbit, spb = 1024, 1 << 14, 16
+bits = torch.randint(0, 2, (nchan, nbit), device=dev, dtype=torch.uint8)
+mod = torch.zeros(nchan, nbit * spb, dtype=torch.float64, device=dev)
+t = timed(lambda: device.am_modulate(bits, mod))
+tot = nchan * nbit * spb
+rows.append({"kernel": "am_modulate (1024 ch x 2^14 bits x 16 samples per bit)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
+             "algorithmic_GBps": 8.0 * tot / t / 1e9, "frac_of_8TBps": 8.0 * tot / t / 1e9 / PEAK})
+wm, wsp = device.fm_tables(2.0e6, 19000.0, 20000.0, spb, True)
+wm, wsp = torch.tensor(wm, device=dev), torch.tensor(wsp, device=dev)
+t = timed(lambda: device.fm_modulate(bits, wm, wsp, mod))
+rows.append({"kernel": "fm_modulate (1024 ch x 2^14 bits x 16 samples per bit)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
+             "algorithmic_GBps": 8.0 * tot / t / 1e9, "frac_of_8TBps": 8.0 * tot / t / 1e9 / PEAK})
+del mod, bits
+for kind, tag in ((_lib.QPSK, "QPSK"), (_lib.BPSK, "BPSK")):
+    nchan, n = 1 << 14, 1 << 12
+    xq = torch.randn(nchan, n, 2, device=dev, dtype=torch.float64) * 0.3
+    bank = device.PskBank(kind, nchan, n)
+    dec = torch.zeros(nchan, bank.n_dec, dtype=torch.uint8, device=dev)
+    m = n // 4
+    mf = torch.zeros(nchan, m, 2, dtype=torch.float64, device=dev)
+    vp = lambda t_: C.c_void_p(t_.data_ptr())  # noqa: E731
+    st_ = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+    tot = nchan * n
+    for name, fn, b in (("matched filter", lambda: L.sdrx_psk_matched_filter_dev(vp(xq), n, nchan, n, vp(mf), m, st_()), 20.0),
+                        ("timing + carrier loops", lambda: L.sdrx_psk_loops_dev(kind, vp(mf), m, nchan, m, vp(bank.states), vp(dec), bank.n_dec, 1, 1, st_()), 4.125),
+                        ("ambiguity pass", lambda: L.sdrx_psk_ambiguity_dev(kind, vp(dec), (m + 1) // 2, nchan, bank.n_dec, vp(bank.states), st_()), 0.125),
+                        ("whole chain (sdrx_psk_demod_dev)", lambda: bank.demod(xq, dec), 16.125)):
+        t = timed(fn, iters=40, warm=10)
+        rows.append({"kernel": f"cfg3 {tag} {name} (2^14 ch x 2^12)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
+                     "algorithmic_GBps": b * tot / t / 1e9, "frac_of_8TBps": b * tot / t / 1e9 / PEAK})
+    del xq, mf, dec, bank
 print(json.dumps({"peak_GBps": PEAK, "rows": rows}, indent=1))

@@ -58,38 +58,69 @@ int launch_am_modulate(const uint8_t *bits, size_t len, size_t nchan, size_t in_
     return SDRX_OK;
 }
 
-// One workgroup per run of bits; both tables staged in LDS once (FM_MAX_SPB doubles each), then every wave copies
-// whole bits: lane l writes table sample l, l + 64, ... of its bit (coalesced 512-byte rows).
+// One workgroup per run of `bpw` bits; both tables (up to FM_MAX_SPB_LDS doubles each) and the run's bits are staged in
+// LDS once, then the run's bpw * spb outputs are written as one flat stream: a lane writes two consecutive doubles per
+// step whatever spb is (a wave stores 1 KB per instruction; with one lane per table sample, spb = 16 used a quarter of
+// every wave and reached 0.38 of the HBM peak).
 constexpr unsigned FM_MAX_SPB_LDS = 8192; // 2 x 64 KB of LDS; longer bits read the tables from global memory (L2)
-constexpr unsigned FM_BITS_PER_WG = 64;
+constexpr unsigned FM_MAX_BPW = 1024;
 
 __global__ void __launch_bounds__(256) fm_modulate_kernel(const uint8_t *__restrict__ bits, size_t len, size_t in_pitch,
                                                           const double *__restrict__ w_mark,
-                                                          const double *__restrict__ w_space, unsigned spb,
+                                                          const double *__restrict__ w_space, unsigned spb, unsigned bpw,
                                                           double *__restrict__ out, size_t out_pitch, int in_lds)
 {
-    extern __shared__ __align__(16) double tab[]; // [0, spb) mark, [spb, 2 spb) space
+    extern __shared__ __align__(16) double tab[]; // [0, spb) mark, [spb, 2 spb) space (when in_lds)
+    __shared__ uint8_t sel[FM_MAX_BPW];           // 1: space (FM.h:62: `if (data_in[i] == 0)` selects the space wave)
     const size_t chan = blockIdx.y;
-    const uint8_t *b = bits + chan * in_pitch;
-    double *o = out + chan * out_pitch;
+    const size_t i0 = (size_t)blockIdx.x * bpw;
+    const unsigned nb = (unsigned)((len - i0) < (size_t)bpw ? (len - i0) : (size_t)bpw);
+    const uint8_t *b = bits + chan * in_pitch + i0;
+    double *o = out + chan * out_pitch + i0 * (size_t)spb;
+    for (unsigned k = threadIdx.x; k < nb; k += blockDim.x) sel[k] = b[k] == 0 ? 1 : 0;
     if (in_lds) {
         for (unsigned k = threadIdx.x; k < spb; k += blockDim.x) {
             tab[k] = w_mark[k];
             tab[spb + k] = w_space[k];
         }
-        __syncthreads();
     }
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    const size_t i0 = (size_t)blockIdx.x * FM_BITS_PER_WG;
-    for (size_t i = i0 + wave; i < i0 + FM_BITS_PER_WG && i < len; i += waves) {
-        const bool mark = b[i] != 0; // FM.h:62: `if (data_in[i] == 0)` selects the space wave
-        double *dst = o + i * (size_t)spb;
-        if (in_lds) {
-            const double *src = tab + (mark ? 0u : spb);
-            for (unsigned k = lane; k < spb; k += 64) __builtin_nontemporal_store(src[k], dst + k);
-        } else {
-            const double *src = mark ? w_mark : w_space;
-            for (unsigned k = lane; k < spb; k += 64) __builtin_nontemporal_store(src[k], dst + k);
+    __syncthreads();
+    const unsigned long long total = (unsigned long long)nb * spb;
+    auto value = [&](unsigned long long p) -> double {
+        const unsigned i = (unsigned)(p / spb), k = (unsigned)(p - (unsigned long long)i * spb);
+        if (in_lds) return tab[(sel[i] ? spb : 0u) + k];
+        return (sel[i] ? w_space : w_mark)[k];
+    };
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const unsigned head = ((((size_t)o) & 15) == 0) ? 0u : 1u; // a run that starts 8 bytes off a 16-byte boundary:
+    if (head && threadIdx.x == 0) o[0] = value(0);             // one double first, then pairs
+    if (total < (1ull << 32)) {
+        // (bit, sample) of a lane's pair advance by the same step every turn: one division per lane, none per pair
+        const unsigned tot = (unsigned)total, step = 2u * blockDim.x, qstep = step / spb, rstep = step - qstep * spb;
+        unsigned p = head + 2u * threadIdx.x;
+        unsigned i = p / spb, k = p - i * spb;
+        auto at = [&](unsigned bi, unsigned bk) -> double {
+            if (in_lds) return tab[(sel[bi] ? spb : 0u) + bk];
+            return (sel[bi] ? w_space : w_mark)[bk];
+        };
+#pragma unroll 4
+        for (; p < tot; p += step) {
+            const double v0 = at(i, k);
+            if (p + 1 < tot) {
+                const bool wrap = k + 1 == spb;
+                __builtin_nontemporal_store(v2{v0, at(wrap ? i + 1 : i, wrap ? 0u : k + 1)}, (v2 *)(o + p));
+            } else {
+                o[p] = v0;
+            }
+            i += qstep;
+            k += rstep;
+            if (k >= spb) { k -= spb; i++; }
+        }
+    } else {
+        for (unsigned long long p = head + 2ull * threadIdx.x; p < total; p += 2ull * blockDim.x) {
+            const double v0 = value(p);
+            if (p + 1 < total) __builtin_nontemporal_store(v2{v0, value(p + 1)}, (v2 *)(o + p));
+            else o[p] = v0;
         }
     }
 }
@@ -103,14 +134,17 @@ int launch_fm_modulate(const uint8_t *bits, size_t len, size_t nchan, size_t in_
     }
     if (len == 0 || nchan == 0 || spb == 0) return SDRX_OK;
     if (spb > 0x7fffffffULL || nchan > 65535) return SDRX_EUNSUPPORTED;
-    const size_t blocks = (len + FM_BITS_PER_WG - 1) / FM_BITS_PER_WG;
+    // bits per workgroup: at least 64, and enough that a workgroup writes >= 4096 samples (32 KB)
+    size_t bpw = (4096 + spb - 1) / spb;
+    bpw = bpw < 64 ? 64 : (bpw > FM_MAX_BPW ? FM_MAX_BPW : bpw);
+    const size_t blocks = (len + bpw - 1) / bpw;
     if (blocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
     const int in_lds = spb <= FM_MAX_SPB_LDS;
     const size_t lds = in_lds ? 2 * spb * sizeof(double) : 0;
     if (lds > 48 * 1024)
         SDRX_HIP(hipFuncSetAttribute((const void *)fm_modulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fm_modulate_kernel, dim3((unsigned)blocks, (unsigned)nchan), dim3(256), lds, s, bits, len, in_pitch,
-                       w_mark, w_space, (unsigned)spb, out, out_pitch, in_lds);
+                       w_mark, w_space, (unsigned)spb, (unsigned)bpw, out, out_pitch, in_lds);
     SDRX_HIP(hipGetLastError());
     note_kernel("fm_modulate_kernel");
     return SDRX_OK;

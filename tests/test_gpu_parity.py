@@ -1239,9 +1239,11 @@ def test_am_fm_modulator_kernels_vs_oracle():
         for c in range(nchan):
             want = O.am_modulate(bits[c], len_mod, np.full(len_mod + 5, -5.5))
             assert np.array_equal(got[c], want), (nchan, nb, len_mod, c)
-    for spb, tx, mark, space in ((100, 100.0, 20.0, 10.0), (1, 10e6, 19000.0, 20000.0), (7, 2e6, 19000.0, 20000.0),
-                                 (2000, 10e6, 19000.0, 20000.0), (9001, 10e6, 19000.0, 20000.0)):
-        nchan, nb = 3, 70
+    for spb, tx, mark, space, nb in ((100, 100.0, 20.0, 10.0, 70), (1, 10e6, 19000.0, 20000.0, 70), (7, 2e6, 19000.0, 20000.0, 70),
+                                     (2000, 10e6, 19000.0, 20000.0, 70), (9001, 10e6, 19000.0, 20000.0, 70),
+                                     (16, 2e6, 19000.0, 20000.0, 3001), (1, 2e6, 19000.0, 20000.0, 2500),
+                                     (101, 2e6, 19000.0, 20000.0, 500)):  # several workgroups per row, odd run starts
+        nchan = 3
         bits = rng.integers(0, 2, (nchan, nb)).astype(np.uint8)
         bits[0, :3] = [0, 1, 255]  # any non-zero byte is a mark (FM.h:62 tests == 0)
         w1, w2 = device.fm_tables(tx, mark, space, spb, True)
