@@ -337,7 +337,9 @@ static const size_t MF_T = 129, MF_STATE = 2 * (MF_T - 1) + 2;
 
 extern "C" size_t sdrx_psk_work_bytes(size_t n, size_t nchan)
 {
-    // matched-filter output | zero-history rows | throw-away state rows | the carrier loop's call-locals (block pipeline)
+    // matched-filter output | two state-row areas no kernel touches any more (the matched filter is a one-shot FIR job;
+    // kept so that the size callers allocate, and the layout behind it, stay what they were) | the carrier loop's
+    // call-locals (block pipeline)
     return align256(nchan * (n / 4) * 2 * sizeof(double)) + 2 * align256(nchan * MF_STATE * sizeof(double)) +
            align256(nchan * 4 * sizeof(double));
 }
