@@ -421,7 +421,10 @@ def extra_configs(torch, args, dev, L):
     """cfg1 / cfg3 (QPSK and BPSK) / cfg4 (the N = 1 point of the sharded curve) / cfg5 (VALU exact, MFMA), a few steps
     each, so that the driver's box times them too.  Each entry: Msamples/s, ms per launch, fractions of the roofs."""
     out = {}
-    runs = [("cfg1", []), ("cfg3", []), ("cfg3_bpsk", ["--bpsk"]), ("cfg4", []), ("cfg5", []), ("cfg5_mfma", ["--mfma"])]
+    # cfg3's 2^26 samples: as 2^14 channels x 2^12 (enough channels to put a wave pair on half of the SIMDs) and as the
+    # 1024 channels x 2^16 of SURVEY 8d (16 wave pairs walking 16384 serial loop steps each: latency-bound by design)
+    runs = [("cfg1", []), ("cfg3", []), ("cfg3_bpsk", ["--bpsk"]), ("cfg3_1024ch", ["--channels", "1024"]), ("cfg4", []),
+            ("cfg5", []), ("cfg5_mfma", ["--mfma"])]
     for name, flags in runs:
         a = parse_args(["--workload", name.split("_")[0], "--steps", "20", "--warmup", "5"] + flags)
         try:
