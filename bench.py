@@ -10,7 +10,8 @@ from step to step.  The line also carries short runs of the other BASELINE confi
 
 N > 1: BASELINE.json configs[3] (cfg4): 1024 independent channels x 2^20 samples of the same chain, block-partitioned
 over the ranks (sdr_amd.shard.partition: rank g owns channels [g*1024/N, (g+1)*1024/N)) -- strong scaling, no data-path
-collective; torch.distributed (RCCL) carries only the barrier, the max-over-ranks and the unit count.
+collective; torch.distributed carries only the barrier, the max-over-ranks and the unit count (over gloo as CPU
+tensors by default, RCCL left for GPU tensors: --backend).
 `--gpus 1 --workload cfg4` is the N = 1 point of that curve.
 
 One process per GPU.  Under `python -m torch.distributed.run ... bench.py --gpus N` every rank runs worker().  Started
@@ -45,9 +46,12 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="f32: the fp32 twins (cfg1, cfg2, cfg4)")
     ap.add_argument("--ingest", default="fp", choices=["fp", "u8"],
                     help="u8: the input is the radio's raw uint8 {I,Q} stream, converted on load (cfg1, cfg2, cfg4)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for the barrier / max-over-ranks (gloo + SDRX_BENCH_SHARE_GPU=1: "
-                         "rehearse the multi-rank path on a one-GPU box, every rank on cuda:0)")
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
+                    help="torch.distributed backend.  The data path has no collective: the only traffic between ranks is "
+                         "the timing barrier and two scalars.  auto (default): process group 'cpu:gloo,cuda:nccl' -- those "
+                         "go over gloo as CPU tensors, RCCL stays available for GPU tensors (shard.gather_bits) and is not "
+                         "initialised unless used; nccl: barrier and scalars as GPU tensors over RCCL; gloo (+ "
+                         "SDRX_BENCH_SHARE_GPU=1): rehearse the multi-rank path on a one-GPU box, every rank on cuda:0")
     ap.add_argument("--shard", action="store_true", help="(kept for older command lines: cfg4 is always sharded)")
     ap.add_argument("--weak", action="store_true",
                     help="cfg4: every rank runs its own 1024 channels x 2^18 instead of a share of 1024 x 2^20")
@@ -223,13 +227,13 @@ def build_workload(wl, args, rank, world, dev):
     return w
 
 
-def timed_steps(torch, step, warmup, steps, dist=None):
+def timed_steps(torch, step, warmup, steps, barrier=None):
     """-> (wall seconds between the barriers, HIP-event milliseconds on the launch stream) for `steps` steps."""
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    if barrier is not None:
+        barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -238,8 +242,8 @@ def timed_steps(torch, step, warmup, steps, dist=None):
         step()
     ev1.record()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    if barrier is not None:
+        barrier()
     torch.cuda.synchronize()
     return time.perf_counter() - t0, ev0.elapsed_time(ev1)
 
@@ -367,8 +371,10 @@ def worker(args):
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
+        elif args.backend == "gloo":
             dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     device.init(local_rank)
@@ -377,7 +383,10 @@ def worker(args):
 
     wl = args.workload or ("cfg2" if world == 1 else "cfg4")
     w = build_workload(wl, args, rank, world, dev)
-    dt, ev_ms = timed_steps(torch, w["step"], args.warmup, args.steps, dist)
+    barrier = None
+    if dist is not None:  # (an all-reduce of one element on the reduction device: with the mixed backend dist.barrier()
+        barrier = lambda: dist.all_reduce(torch.zeros(1, device=red_dev))  # noqa: E731   would bring up RCCL for nothing)
+    dt, ev_ms = timed_steps(torch, w["step"], args.warmup, args.steps, barrier)
     kernel = L.sdrx_last_kernel().decode()  # what the launcher picked for this shape (the last step's launches)
     dt = shard.max_over_ranks(dt, device=red_dev)
 
@@ -413,7 +422,7 @@ def worker(args):
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(taps, D, threads, 25 if threads <= 16 else 23)
         print(json.dumps(res), flush=True)
     if dist is not None:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

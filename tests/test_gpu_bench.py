@@ -48,3 +48,12 @@ def test_bench_single_gpu_point_of_the_same_curve_and_a_failing_rank():
     p = _run(["--gpus", "2", "--backend", "gloo", "--workload", "cfg3", "--dtype", "f32", "--steps", "1", "--warmup", "0"])
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_bench_default_backend_keeps_the_control_traffic_on_gloo():
+    """No --backend: the process group is 'cpu:gloo,cuda:nccl' and the barrier / scalars travel as CPU tensors, so two
+    ranks that share one GPU (where RCCL could not form a communicator) still run: RCCL is never brought up."""
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--log2n", "13", "--channels", "8"])
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    r = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert r["n_gpus"] == 2 and r["config"]["channels_per_gpu"] == 4
