@@ -148,7 +148,7 @@ __device__ __forceinline__ int phase_step(PhaseState &p, double re, double im, b
         p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
         p.plf_x = val;
         p.plf_y = p.temp;
-        return (SDRX_SGN(p.tr) < 0) ? 1 : 0;
+        return (p.tr < 0.0) ? 1 : 0; // SIGN_FUNC(tr) < 0 is tr < 0 (a NaN has sign +1: neither)
     } else { // QPSK.cpp:361-373: loop filter first, from the previous product
         const double val = 8.0 * (SDRX_SGN(p.ti) * p.tr - SDRX_SGN(p.tr) * p.ti);
         p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
@@ -158,8 +158,12 @@ __device__ __forceinline__ int phase_step(PhaseState &p, double re, double im, b
         p.dds_delay = p.dds_delay + p.temp;
         p.tr = re * cs - im * sn;
         p.ti = im * cs + re * sn;
-        const double sr = SDRX_SGN(p.tr), si = SDRX_SGN(p.ti); // QPSK.cpp:396-414
-        return (sr < 0 && si < 0) ? 3 : ((sr > 0 && si < 0) ? 2 : ((sr < 0 && si > 0) ? 1 : 0));
+        // QPSK.cpp:396-414 compares the two SIGN_FUNC values; written on the samples themselves so that the compares
+        // the next step's SIGN_FUNCs need anyway are the only ones: sign < 0 is v < 0, sign > 0 is !(v < 0) && !(v == 0)
+        // (which holds for a NaN, whose SIGN_FUNC is +1)
+        const bool rn = p.tr < 0.0, in = p.ti < 0.0;
+        const bool rp = !rn && !(p.tr == 0.0), ip = !in && !(p.ti == 0.0);
+        return (rn && in) ? 3 : ((rp && in) ? 2 : ((rn && ip) ? 1 : 0));
     }
 }
 
