@@ -54,7 +54,7 @@ n1 = 1200000  # one radio, the receiver's block (m_SampleRate / 2)
 t = timed(lambda: device.ones_zeros_confidence(re[:n1].view(1, -1), im[:n1].view(1, -1), 500000, cc1))
 rows.append({"kernel": "ones_zeros confidence walk (1 ch x 1.2M, the receiver's block)", "samples": n1, "ms": t * 1e3,
              "Msamples_per_s": n1 / t / 1e6, "algorithmic_GBps": 16.0 * n1 / t / 1e9, "frac_of_8TBps": 16.0 * n1 / t / 1e9 / PEAK})
-for ds in (100, 2000):
+for ds in (100, 250, 2000):
     w1 = torch.randn(ds, dtype=torch.float64, device=dev)
     w2 = torch.randn(ds, dtype=torch.float64, device=dev)
     out = torch.zeros(n // ds, dtype=torch.uint8, device=dev)

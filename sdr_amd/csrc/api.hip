@@ -63,6 +63,7 @@ Tuning &tuning()
         x.psk_split = env_int("SDRX_PSK_SPLIT", d.psk_split);
         x.psk_overlap = env_int("SDRX_PSK_OVERLAP", d.psk_overlap);
         x.psk_pieces = env_int("SDRX_PSK_PIECES", d.psk_pieces);
+        x.fsk_rows = env_int("SDRX_FSK_ROWS", d.fsk_rows);
         x.iir_cw = env_int("SDRX_IIR_CW", d.iir_cw);
         return x;
     }();
@@ -163,6 +164,7 @@ extern "C" int sdrx_tune(const char *name, const char *value)
     else if (strcmp(name, "SDRX_PSK_SPLIT") == 0) t.psk_split = dflt ? d.psk_split : v;
     else if (strcmp(name, "SDRX_PSK_OVERLAP") == 0) t.psk_overlap = dflt ? d.psk_overlap : v;
     else if (strcmp(name, "SDRX_PSK_PIECES") == 0) t.psk_pieces = dflt ? d.psk_pieces : v;
+    else if (strcmp(name, "SDRX_FSK_ROWS") == 0) t.fsk_rows = dflt ? d.fsk_rows : v;
     else if (strcmp(name, "SDRX_IIR_CW") == 0) t.iir_cw = dflt ? d.iir_cw : v;
     else {
         set_error("sdrx_tune: unknown switch %s", name);

@@ -273,67 +273,86 @@ __global__ void __launch_bounds__(FSK_NT) fsk_corr_kernel(const double *__restri
 // contiguous bytes, loaded 4 runs per instruction into registers one chunk AHEAD of the arithmetic,
 // transposed through the wave's own LDS slice (pitch 17 doubles: conflict-free both ways), and each
 // lane then adds its bit's 16 products in the reference's order.  Taps come by scalar loads.
+// ROWS = 64 bits per wave (chunks of 16 samples) or ROWS = 16 (chunks of 64 samples: a load instruction is one bit's 512
+// contiguous bytes, only 16 lanes do the arithmetic).  Windows that are not multiples of the 128-byte line make every
+// line the target of two consecutive 16-sample chunks (FETCH_SIZE 1.52 x the input at ds = 100); with 64-sample chunks
+// it is five lines per four, and the loads are four times longer runs: 0.54 -> 0.73 of the HBM peak at ds = 250.
 constexpr int FSKW_KC = 16;
 
+template <int ROWS>
 __global__ void __launch_bounds__(256) fsk_corr_wave_kernel(const double *__restrict__ x, const double *__restrict__ w1,
                                                             const double *__restrict__ w2, uint8_t *__restrict__ out,
                                                             size_t nbits, unsigned ds)
 {
-    constexpr int KC = FSKW_KC, PITCH = KC + 1;
-    __shared__ double smem[4 * 64 * PITCH];
+    constexpr int KC = 1024 / ROWS, PITCH = KC + 1;
+    constexpr int LPR = KC < 64 ? KC : 64; // lanes per row in a load instruction
+    constexpr int RPI = 64 / LPR;          // rows per load instruction
+    constexpr int NI = ROWS / RPI;         // load instructions per chunk (16)
+    __shared__ double smem[4 * ROWS * PITCH];
     const unsigned lane = threadIdx.x & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *lds = smem + wave * 64 * PITCH;
-    const size_t bit0 = ((size_t)blockIdx.x * 4 + wave) * 64;
+    double *lds = smem + wave * ROWS * PITCH;
+    const size_t bit0 = ((size_t)blockIdx.x * 4 + wave) * ROWS;
     if (bit0 >= nbits) return;
     const unsigned nchunks = (ds + KC - 1) / KC;
-    // lane's element i of a chunk: row 4 i + lane / 16, sample lane % 16 of the chunk
-    const unsigned k_ld = lane & 15, row_ld = lane >> 4;
-    const double *xrow[KC]; // row bases of the 16 rows this lane loads from
-    bool row_ok[KC];
+    // lane's element i of a chunk: row RPI i + lane / LPR, sample lane % LPR of the chunk
+    const unsigned k_ld = lane % LPR, row_ld = lane / LPR;
+    const double *xrow[NI]; // row bases of the rows this lane loads from
+    bool row_ok[NI];
 #pragma unroll
-    for (int i = 0; i < KC; i++) {
-        const size_t b = bit0 + 4 * i + row_ld;
+    for (int i = 0; i < NI; i++) {
+        const size_t b = bit0 + RPI * i + row_ld;
         row_ok[i] = b < nbits;
         xrow[i] = x + (row_ok[i] ? b : bit0) * (size_t)ds + k_ld;
     }
-    double regs[KC];
+    double regs[NI];
     auto load_chunk = [&](unsigned chunk) {
         const unsigned c_lo = chunk * KC;
         const bool k_ok = c_lo + k_ld < ds; // only the window's top chunk can be partial
 #pragma unroll
-        for (int i = 0; i < KC; i++) regs[i] = (k_ok && row_ok[i]) ? xrow[i][c_lo] : 0.0;
+        for (int i = 0; i < NI; i++) regs[i] = (k_ok && row_ok[i]) ? xrow[i][c_lo] : 0.0;
     };
     load_chunk(nchunks - 1);
     double op1 = 0.0, op2 = 0.0;
     for (int chunk = (int)nchunks - 1; chunk >= 0; chunk--) {
 #pragma unroll
-        for (int i = 0; i < KC; i++) lds[(4 * i + row_ld) * PITCH + k_ld] = regs[i];
+        for (int i = 0; i < NI; i++) lds[(RPI * i + row_ld) * PITCH + k_ld] = regs[i];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (chunk > 0) load_chunk((unsigned)chunk - 1); // in flight during this chunk's arithmetic
         const unsigned c_lo = (unsigned)chunk * KC;
-        const double *row = lds + lane * PITCH;
-        if (c_lo + KC <= ds) {
-            double v[KC];
+        if (ROWS == 64 || lane < ROWS) {
+            const double *row = lds + lane * PITCH;
+            if (c_lo + KC <= ds) {
+                if constexpr (KC == 16) {
+                    double v[KC];
 #pragma unroll
-            for (int k = 0; k < KC; k++) v[k] = row[k];
+                    for (int k = 0; k < KC; k++) v[k] = row[k];
 #pragma unroll
-            for (int k = KC - 1; k >= 0; k--) { // last sample first: FM.h:94-100
-                op1 += v[k] * w1[c_lo + k];
-                op2 += v[k] * w2[c_lo + k];
-            }
-        } else {
-            for (int k = (int)(ds - c_lo) - 1; k >= 0; k--) {
-                const double v = row[k];
-                op1 += v * w1[c_lo + k];
-                op2 += v * w2[c_lo + k];
+                    for (int k = KC - 1; k >= 0; k--) { // last sample first: FM.h:94-100
+                        op1 += v[k] * w1[c_lo + k];
+                        op2 += v[k] * w2[c_lo + k];
+                    }
+                } else {
+#pragma unroll 16
+                    for (int k = KC - 1; k >= 0; k--) {
+                        const double v = row[k];
+                        op1 += v * w1[c_lo + k];
+                        op2 += v * w2[c_lo + k];
+                    }
+                }
+            } else {
+                for (int k = (int)(ds - c_lo) - 1; k >= 0; k--) {
+                    const double v = row[k];
+                    op1 += v * w1[c_lo + k];
+                    op2 += v * w2[c_lo + k];
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // these reads stay above the next chunk's writes
         __builtin_amdgcn_wave_barrier();
     }
-    if (bit0 + lane < nbits) out[bit0 + lane] = (op1 > op2) ? 1 : 0; // FM.h:139 (repaired)
+    if (lane < ROWS && bit0 + lane < nbits) out[bit0 + lane] = (op1 > op2) ? 1 : 0; // FM.h:139 (repaired)
 }
 
 // Measured and left as is (round 2, profiles/r02_fsk_study.json): windows that are not a multiple of the 128-byte line
@@ -352,11 +371,22 @@ int launch_fm_demod(const double *re, const double *w1, const double *w2, uint8_
     size_t nbits = n / ds; // FM.h:114
     if (nbits == 0) return SDRX_OK;
     if (ds >= (size_t)FSKW_KC) {
-        const size_t wblocks = (nbits + 255) / 256;
+        const int rows_tune = tuning().fsk_rows; // 0 auto | 64 | 16
+        // measured (2^28 samples, fraction of the HBM peak, 64 / 16 bits per wave): ds = 64 0.78 / 0.71, 100 0.62 / 0.66,
+        // 128 0.77 / 0.78, 250 0.54 / 0.73, 333 0.55 / 0.74, 500 0.56 / 0.70, 1000 0.63 / 0.65, 2000 0.61 / 0.46; a
+        // single radio's block with long bits (1.2 M samples, ds = 2000: 600 bits) 155 / 114 us
+        const bool mid = ds >= 96 && ds <= 1200, tiny = nbits < 4096;
+        const int rows = ds >= 64 && (rows_tune == 16 || (rows_tune == 0 && (mid || tiny))) ? 16 : 64;
+        const size_t per_wg = 4 * (size_t)rows, wblocks = (nbits + per_wg - 1) / per_wg;
         if (wblocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
-        hipLaunchKernelGGL(fsk_corr_wave_kernel, dim3((unsigned)wblocks), dim3(256), 0, s, re, w1, w2, out, nbits,
-                           (unsigned)ds);
+        if (rows == 64)
+            hipLaunchKernelGGL(fsk_corr_wave_kernel<64>, dim3((unsigned)wblocks), dim3(256), 0, s, re, w1, w2, out, nbits,
+                               (unsigned)ds);
+        else
+            hipLaunchKernelGGL(fsk_corr_wave_kernel<16>, dim3((unsigned)wblocks), dim3(256), 0, s, re, w1, w2, out, nbits,
+                               (unsigned)ds);
         SDRX_HIP(hipGetLastError());
+        note_kernel("fsk_corr_wave_kernel", rows, 0, 0, 0);
         return SDRX_OK;
     }
     size_t blocks = (nbits + FSK_NT - 1) / FSK_NT;

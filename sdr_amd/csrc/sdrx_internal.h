@@ -42,6 +42,7 @@ struct Tuning {
     int fir_fill = 1;         // SDRX_FIR_FILL: 0 = interior tiles stage through the general (bounds-tested) path too
     int fir_ct = 1;           // SDRX_FIR_CT: 0 = never use the compile-time (T = 129, D = 4) instance of the tile kernel
     int psk_split = -1;       // SDRX_PSK_SPLIT: -1 auto, 0 one-wave loops, 1 two-wave loops
+    int fsk_rows = 0;         // SDRX_FSK_ROWS: bits per wave of the FSK correlator (0 auto, 64, 16)
     int psk_pieces = 4;       // SDRX_PSK_PIECES: pieces a call is cut into by the block pipeline (2..16)
     int psk_overlap = -1;     // SDRX_PSK_OVERLAP: -1 auto, 0 one stream, 1 block pipeline on two streams
     int iir_cw = 0;           // SDRX_IIR_CW: rows per wave of the recurrences (0 = by bank size)

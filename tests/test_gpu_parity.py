@@ -1709,3 +1709,33 @@ def test_fir_job_without_state_rows_is_a_one_shot_call():
     assert Lx.sdrx_fir_fmdisc_dev(C.byref(j)) == -1
     j.state_in = C.c_void_p(ch.state[0].data_ptr())
     assert Lx.sdrx_fir_dev(C.byref(j)) == -1  # one of the two rows only
+
+
+@pytest.mark.parametrize("ds", [64, 65, 100, 333, 2000])
+def test_fm_demod_bits_per_wave_forms_match_oracle(ds, tune):
+    """The FSK correlator's wave kernel with 64 and with 16 bits per wave (the second is picked for calls with few
+    bits): the oracle's bits through the host class either way, ragged bit counts, and the same bits as each other at
+    the device layer on integer noise (exact ties) with random taps."""
+    rng = np.random.default_rng(2000 + ds)
+    nbits = 333
+    bits = rng.integers(0, 2, nbits).astype(np.uint8)
+    x = O.fm_modulate(2.0e6, 19000.0, 20000.0, bits, ds) * 40 + rng.normal(0, 1.0, nbits * ds)
+    x = np.concatenate([x, rng.normal(0, 1, ds // 2)])
+    want = O.fm_demodulate(2.0e6, 19000.0, 20000.0, x, ds)
+    for rows in ("64", "16", "0"):
+        tune("SDRX_FSK_ROWS", rows)
+        out = np.zeros(nbits + 4, dtype=np.uint8)
+        m = host.FM(10e6, 2.0e6).demodulate(x, x, out, x.size, ds)
+        assert m == nbits and np.array_equal(out[:m], want), rows
+    w1 = torch.tensor(rng.normal(0, 1, ds), device="cuda")
+    w2 = torch.tensor(rng.normal(0, 1, ds), device="cuda")
+    for nb in (1, 15, 16, 17, 63, 65, 1000):
+        noise = torch.tensor(rng.integers(-3, 4, nb * ds).astype(np.float64), device="cuda")
+        got = {}
+        for rows in ("64", "16"):
+            tune("SDRX_FSK_ROWS", rows)
+            o = torch.full((nb + 3,), 9, dtype=torch.uint8, device="cuda")
+            device.fm_demod(noise, w1, w2, o, ds)
+            got[rows] = o.cpu().numpy()
+            assert (got[rows][nb:] == 9).all()
+        assert np.array_equal(got["64"], got["16"]), nb
