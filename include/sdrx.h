@@ -284,7 +284,7 @@ void sdrx_psk_state_init_qpsk(sdrx_psk_state *s, const double *uw64, size_t uw_l
  *   states    device, nchan sdrx_psk_state (read and updated in place)
  *   out       device uint8: decisions 0/1 (BPSK) or 0..3 (QPSK), n/8 per channel, pitch out_pitch
  *   work      device workspace of sdrx_psk_work_bytes(n, nchan) bytes
- * Banks of few channels with long blocks (nchan <= 4096 and n >= 8192) are cut in time into pieces whose matched
+ * Banks of few channels with long blocks (nchan <= 8192 and n >= 8192) are cut in time into pieces whose matched
  * filter runs beside the previous piece's loops on a side stream of the library (created on the first such call on a
  * device; ordered with `stream` by events, so the call still behaves as one operation of `stream`; results are those
  * of the one-stream form bit for bit).  sdrx_tune("SDRX_PSK_OVERLAP", "0") keeps everything on `stream`; a caller that

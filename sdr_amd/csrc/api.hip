@@ -426,11 +426,11 @@ static int psk_demod_common(int kind, const double *iq, size_t n, size_t nchan, 
     const Tuning &tune = tuning();
     const int want = tune.psk_overlap;
     // Pays only where the loops dominate (few channels, long blocks): there the matched filter hides behind them
-    // (2^12 channels x 2^14 samples: 1.63 -> 1.51 ms).  Where the two take similar time (2^14 x 2^12) the loop waves,
+    // (round 2's final kernels: 2^13 channels x 2^13 samples 0.79 -> 0.76 ms, 2^12 x 2^14 1.20 -> 1.11, 2^10 x 2^16 3.77 -> 3.69).  Where the two take similar time (2^14 x 2^12) the loop waves,
     // sharing their SIMDs with matched-filter waves, slow down by as much as the overlap saves (0.74 -> 0.89 ms;
     // profiles/r02_cfg3_overlap_trace.json), s_setprio and a high-priority queue notwithstanding: off by default there.
     // Giving each stage CUs of its own (CU-masked queues) is worse still: profiles/r02_cfg3_cumask.json.
-    const bool overlap = may_overlap && want != 0 && m >= 512 && (want > 0 || (nchan <= (1u << 12) && m >= 2048));
+    const bool overlap = may_overlap && want != 0 && m >= 512 && (want > 0 || (nchan <= (1u << 13) && m >= 2048));
     if (!overlap) {
         int rc = mf_launch(iq, n, nchan, in_pitch, mf, m, zst, dst, s, offs_buf, offs_cap);
         if (rc) return rc;

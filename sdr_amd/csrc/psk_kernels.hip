@@ -419,24 +419,12 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
     sdrx_psk_state *st = states + c;
     uint8_t *d = dec + c * out_pitch;
     const int U = st->uw_size > 64 ? 64 : (st->uw_size < 0 ? 0 : st->uw_size);
-    // short blocks (the one-wave form): the channel's decisions are staged in LDS once, the 16..64 compares of
-    // every position then read LDS instead of issuing a global byte load each
+    // the one-wave form: the channel's decisions pass through LDS in segments of AMB_SEG positions (+ the unique word's
+    // reach), the 16..64 compares of every position then read LDS instead of issuing a global byte load each
     constexpr bool STAGED = NT == 64;
+    constexpr size_t AMB_SEG = 1920, AMB_REACH = 68; // segment + 64 symbols + the word the last position's compare over-reads
     __shared__ __align__(16) uint8_t sd[STAGED ? 2048 + 16 : 16];
-    const uint8_t *src = d;
-    if constexpr (STAGED) {
-        if ((((size_t)d) & 3) == 0) {
-            for (size_t w = tid; w < (m + 3) / 4; w += NT) {
-                unsigned v = 0;
-                if (4 * w + 4 <= m) v = *(const unsigned *)(d + 4 * w);
-                else for (size_t k = 4 * w; k < m; k++) v |= (unsigned)d[k] << (8 * (k - 4 * w));
-                *(unsigned *)(sd + 4 * w) = v;
-            }
-        } else {
-            for (size_t k = tid; k < m; k += NT) sd[k] = d[k];
-        }
-        src = sd;
-    }
+    static_assert(AMB_SEG + AMB_REACH + 16 <= 2048 + 16 && AMB_SEG % 64 == 0, "segment fits the staging row");
     if (tid < 64 && (int)tid < U) {
         const int idx = (kind == SDRX_BPSK) ? (U - 1 - (int)tid) : (63 - (int)tid); // BPSK.cpp:456, QPSK.cpp:428
         for (int k = 0; k < 4; k++) uwc[k][tid] = (uint8_t)st->uw[k][idx];
@@ -472,7 +460,27 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
     }
     int cc0 = s_cc[0], cc1 = s_cc[1], cc2 = s_cc[2], cc3 = s_cc[3], nh = 0; // one-wave form: the counters as wave-uniform values
     if (m >= (size_t)U) {
-        const size_t npos = m - (size_t)U; // i < num_of_points - UW_SIZE
+        const size_t npos_all = m - (size_t)U; // i < num_of_points - UW_SIZE
+      for (size_t seg0 = 0; seg0 < npos_all; seg0 += STAGED ? AMB_SEG : npos_all) {
+        const size_t npos = STAGED ? (npos_all - seg0 < AMB_SEG ? npos_all - seg0 : AMB_SEG) : npos_all;
+        const uint8_t *src = d; // where position 0 of the segment is read from
+        if constexpr (STAGED) {
+            __syncthreads(); // the previous segment's reads are done
+            const uint8_t *g = d + seg0;
+            const size_t cnt = (m - seg0) < (AMB_SEG + AMB_REACH) ? (m - seg0) : (AMB_SEG + AMB_REACH);
+            if ((((size_t)g) & 3) == 0) {
+                for (size_t w = tid; w < (cnt + 3) / 4; w += NT) {
+                    unsigned v = 0;
+                    if (4 * w + 4 <= cnt) v = *(const unsigned *)(g + 4 * w);
+                    else for (size_t k = 4 * w; k < cnt; k++) v |= (unsigned)g[k] << (8 * (k - 4 * w));
+                    *(unsigned *)(sd + 4 * w) = v;
+                }
+            } else {
+                for (size_t k = tid; k < cnt; k += NT) sd[k] = g[k];
+            }
+            __syncthreads();
+            src = sd;
+        }
         for (size_t base = 0; base < npos; base += NT) {
             const size_t i = base + tid;
             int code = -1;
@@ -484,7 +492,7 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
                 unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0;
                 const int nq = (U + 3) >> 2;
                 for (int q = 0; q < nq; q++) {
-                    const unsigned hi = D[a + q + 1]; // at most byte m + 6 of sd[2048 + 16]
+                    const unsigned hi = D[a + q + 1]; // at most byte AMB_SEG + 70 of sd[2048 + 16]
                     unsigned w = __builtin_amdgcn_alignbyte(hi, lo, sh); // row bytes ic + 4q .. ic + 4q + 3
                     lo = hi;
                     const int rem = U - 4 * q;
@@ -537,7 +545,7 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
                         if (cd == 3) { if (++cc3 >= 10) cc3 = 10; } else { if (--cc3 <= 0) cc3 = 0; }
                     }
                     if (hits && (size_t)nh < max_hits && tid == 0)
-                        hits[c * max_hits + nh] = ((unsigned long long)(base + t) << 3) | (unsigned long long)cd;
+                        hits[c * max_hits + nh] = ((unsigned long long)(seg0 + base + t) << 3) | (unsigned long long)cd;
                     nh++;
                 }
             } else {
@@ -564,6 +572,7 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
             __syncthreads();
             }
         }
+      }
     }
     if constexpr (STAGED) {
         if (tid == 0) { s_cc[0] = cc0; s_cc[1] = cc1; s_cc[2] = cc2; s_cc[3] = cc3; s_nh = nh; }
@@ -585,9 +594,12 @@ __global__ void __launch_bounds__(NT) psk_ambiguity_kernel(int kind, uint8_t *__
     const int lut = s_lut;
     if (lut < 0) return;
     if constexpr (STAGED) {
-        if ((((size_t)d) & 3) == 0) { // four decisions per lane from the staged row; the maps on packed bytes
+        if ((((size_t)d) & 3) == 0) { // four decisions per lane; the maps on packed bytes
             for (size_t w = tid; w < (m + 3) / 4; w += NT) {
-                const unsigned v = *(const unsigned *)(sd + 4 * w), b = 0x01010101u;
+                unsigned v = 0;
+                if (4 * w + 4 <= m) v = *(const unsigned *)(d + 4 * w);
+                else for (size_t k = 4 * w; k < m; k++) v |= (unsigned)d[k] << (8 * (k - 4 * w));
+                const unsigned b = 0x01010101u;
                 unsigned o;
                 if (kind == SDRX_BPSK) o = v ^ b;
                 else if (lut == 1) o = ((~v & b) << 1) | ((v >> 1) & b); // {2,0,3,1}: out1 = !in0, out0 = in1
@@ -619,15 +631,16 @@ int launch_psk_ambiguity(int kind, uint8_t *decisions, size_t m, size_t nchan, s
     }
     if (nchan == 0) return SDRX_OK;
     if (nchan > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
-    // short blocks (config 3: 256 decisions per channel): one wave per channel, four times as many channels in flight
-    if (m <= 2048)
+    // one wave per channel (decisions staged through LDS, four symbols per compare) for short rows and for banks with
+    // enough channels to fill the chip with waves; four waves per channel reading global bytes for a few long rows
+    if (m <= 2048 || nchan >= 256)
         hipLaunchKernelGGL(psk_ambiguity_kernel<64>, dim3((unsigned)nchan), dim3(64), 0, s, kind, decisions, m, out_pitch,
                            states, (unsigned long long *)nullptr, (size_t)0);
     else
         hipLaunchKernelGGL(psk_ambiguity_kernel<256>, dim3((unsigned)nchan), dim3(256), 0, s, kind, decisions, m, out_pitch,
                            states, (unsigned long long *)nullptr, (size_t)0);
     SDRX_HIP(hipGetLastError());
-    note_kernel("psk_ambiguity_kernel", kind, m <= 2048 ? 64 : 256);
+    note_kernel("psk_ambiguity_kernel", kind, (m <= 2048 || nchan >= 256) ? 64 : 256);
     return SDRX_OK;
 }
 

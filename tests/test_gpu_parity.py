@@ -1648,9 +1648,13 @@ def test_psk_ambiguity_stage_unique_word_lengths_and_rows(kind, lk):
         bad = np.array(rng.integers(0, 4, 64), dtype=np.float64)
         bad[60] = 7.0  # not a symbol: QPSK.cpp:103 leaves this index at 0 in all four rows
         cases.append((16, bad))
+    # (rows, channels): few channels take the 256-thread form past 2048 decisions, banks of >= 256 channels the one-wave
+    # form for any length (rows staged through LDS in segments of 1920 positions)
+    shapes = [(m, 5) for m in (255, 256, 300, 301, 2048, 2049, 5000)] + [(m, 257) for m in (1921, 3905, 5001)]
     for U, uw in cases:
-        for m in (255, 256, 300, 301, 2048, 2049, 5000):
-            nchan = 5
+        for m, nchan in shapes:
+            if nchan > 5 and U not in (13, 64, 16):
+                continue
             if kind == O.BPSK:
                 word = int(rng.integers(0, 2 ** 63)) if uw is None else uw
                 sts = [O.psk_new(kind, uw=word, uw_len=U, math_mode=O.MATH_SHARED) for _ in range(nchan)]
