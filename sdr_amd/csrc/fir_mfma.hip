@@ -91,7 +91,13 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const MfmaGeom g, const d
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
     constexpr int BSTEP = 256 + 16; // LDS doubles between the blocks' elements (256 samples and their pads)
-    constexpr int U = 4;            // iterations per trip: their loads are issued ahead of the matrix instructions
+    // iterations per trip: their 5 U LDS reads are issued ahead of the trip's 4 U matrix instructions.  Measured on
+    // config 5 (T = 1024: 260 iterations), fraction of the 78.6 TFLOP/s peak: U = 2 0.69, 4 0.77, 8 0.84, 10 0.86, 12 0.86,
+    // 16 0.86 (blocks per wave NB = 3 / 5 / 6 instead of 4: 0.76 / 0.75 / 0.67-0.77)
+#ifndef SDRX_MFMA_U
+#define SDRX_MFMA_U 10
+#endif
+    constexpr int U = SDRX_MFMA_U;
     int it = 0;
     for (; it + U <= NIT; it += U) {
         double a[U], bv[U][NB];
@@ -139,7 +145,10 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const MfmaGeom g, const d
 // fast mode 2 (fp64 MFMA): one launch per rail
 int launch_fir_mfma(const sdrx_fir_job *job, size_t n_out)
 {
-    constexpr int NB = 4;
+#ifndef SDRX_MFMA_NB
+#define SDRX_MFMA_NB 4
+#endif
+    constexpr int NB = SDRX_MFMA_NB;
     const int T = job->num_taps;
     const int H = T - 1;
     hipStream_t stream = (hipStream_t)job->stream;
