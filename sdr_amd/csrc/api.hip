@@ -190,6 +190,8 @@ extern "C" const char *sdrx_last_kernel(void)
             snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s%s>", k.a, lay[k.b & 3], epi[k.c % 3], k.d ? ", fma" : "");
         else if (strcmp(k.family, "fir_tile_kernel_ct129x4") == 0)
             snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s, T=129, D=4 compile-time>", k.a, lay[k.b & 3], epi[k.c % 3]);
+        else if (strcmp(k.family, "fir_tile_kernel_ct64x1") == 0)
+            snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s, T=64, D=1 compile-time>", k.a, lay[k.b & 3], epi[k.c % 3]);
         else if (strncmp(k.family, "psk_loops", 9) == 0)
             snprintf(one, sizeof(one), "%s<%s>", k.family, k.a == SDRX_BPSK ? "BPSK" : "QPSK");
         else if (strcmp(k.family, "psk_ambiguity_kernel") == 0)
