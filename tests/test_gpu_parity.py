@@ -1743,3 +1743,39 @@ def test_fm_demod_bits_per_wave_forms_match_oracle(ds, tune):
             got[rows] = o.cpu().numpy()
             assert (got[rows][nb:] == 9).all()
         assert np.array_equal(got["64"], got["16"]), nb
+
+
+def test_compile_time_window_walk_instances_equal_the_run_time_walk(tune):
+    """The two compile-time instances of the workgroup-tile kernel (T = 64, D = 1 with the AM epilogue: BASELINE config
+    1; T = 129, D = 4 storing: the PSK matched filter) against the run-time walk (SDRX_FIR_CT=0) over three ragged
+    calls with carried state, 3 channels: same bits / samples and same final state, and the kernel that ran is the one
+    meant."""
+    Lx = _lib.lib()
+    rng = np.random.default_rng(64129)
+    for T, D, epi in ((64, 1, "am"), (129, 4, "store")):
+        taps = O.fir_design(O.LPF, T, 2.0e6, 1.0e5)[1] if T == 64 else rng.normal(0, 1, T)
+        res = {}
+        for ct in ("1", "0"):
+            tune("SDRX_FIR_CT", ct)
+            ch = device.FirChain(taps, 3, D)
+            outs = []
+            rs = np.random.default_rng(7)
+            for n in (5000, 3001, 7777):
+                x = torch.tensor(rs.integers(-127, 128, (3, n, 2)).astype(np.float64) * (3.0 if epi == "am" else 0.01), device="cuda")
+                n_out = (n + D - 1) // D
+                if epi == "am":
+                    o = torch.zeros(3, n_out, dtype=torch.uint8, device="cuda")
+                    ch.fir_am(x, o)
+                    outs.append(o.cpu().numpy())
+                else:
+                    o0, o1 = (torch.zeros(3, n_out, dtype=torch.float64, device="cuda") for _ in range(2))
+                    ch.fir(x, o0, o1)
+                    outs.append(np.stack([o0.cpu().numpy(), o1.cpu().numpy()]))
+                name = Lx.sdrx_last_kernel().decode()
+                assert ("compile-time" in name) == (ct == "1"), (name, ct)
+            res[ct] = (outs, ch.state[ch.cur].cpu().numpy())
+        for a, b in zip(res["1"][0], res["0"][0]):
+            assert np.array_equal(a, b), (T, D)
+        assert np.array_equal(res["1"][1], res["0"][1]), (T, D, "state")
+        if epi == "am":
+            assert 0.05 < np.concatenate([o.ravel() for o in res["1"][0]]).mean() < 0.95
