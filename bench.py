@@ -414,7 +414,7 @@ def worker(args):
         torch.cuda.empty_cache()
         if world == 1 and not args.no_extra and wl == "cfg2" and plain:
             res["extra"] = {"configs": extra_configs(torch, args, dev, L),
-                            "note": "short runs (5 warm-up + 20 timed steps) of the other BASELINE configs in this process, "
+                            "note": "short runs (20 warm-up + 50 timed steps) of the other BASELINE configs in this process, "
                                     "after the headline; frac_hbm = algorithmic bytes / launch time / 8 TB/s"}
         if world == 1 and not args.no_cpu and wl == "cfg2" and plain:
             res["cpu_baseline"] = cpu_baseline_cfg2(taps, D)
@@ -435,7 +435,7 @@ def extra_configs(torch, args, dev, L):
     runs = [("cfg1", []), ("cfg3", []), ("cfg3_bpsk", ["--bpsk"]), ("cfg3_1024ch", ["--channels", "1024"]), ("cfg4", []),
             ("cfg5", []), ("cfg5_mfma", ["--mfma"])]
     for name, flags in runs:
-        a = parse_args(["--workload", name.split("_")[0], "--steps", "20", "--warmup", "5"] + flags)
+        a = parse_args(["--workload", name.split("_")[0], "--steps", "50", "--warmup", "20"] + flags)
         try:
             w = build_workload(a.workload, a, 0, 1, dev)
             dt, ev_ms = timed_steps(torch, w["step"], a.warmup, a.steps)
