@@ -30,7 +30,7 @@
 #define SDRX_STAGE_UNR 12
 #endif
 #ifndef SDRX_STEADY_UB
-#define SDRX_STEADY_UB 4
+#define SDRX_STEADY_UB 8 // measured on config 5 (T = 1024, real rail), exact / fma chain: UB = 4 16.4 / 10.9 ms, 8 15.8 / 9.5, 16 20.9 / 10.8
 #endif
 
 namespace sdrx {
