@@ -447,7 +447,7 @@ static int psk_demod_common(int kind, const double *iq, size_t n, size_t nchan, 
         return SDRX_EHIP;
     }
     const int pieces = tune.psk_pieces < 2 ? 2 : (tune.psk_pieces > PSK_PIECES_MAX ? PSK_PIECES_MAX : tune.psk_pieces);
-    const size_t m_piece = (((m + pieces - 1) / pieces) + 15) & ~(size_t)15; // whole ring blocks, even: /2 keeps 0, 2, ...
+    const size_t m_piece = (((m + pieces - 1) / pieces) + 31) & ~(size_t)31; // whole ring blocks (32 samples), even: /2 keeps 0, 2, ...
     hipStream_t s_mf = s, s_lp = pp->side;
     int k = 0;
     for (size_t m0 = 0; m0 < m; m0 += m_piece, k++) {

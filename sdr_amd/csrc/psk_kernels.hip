@@ -255,7 +255,12 @@ __global__ void __launch_bounds__(64) psk_loops_kernel(double2 *__restrict__ mf,
 // j-1 out of it, one s_barrier per block.  With one channel per lane a bank of 2^14 channels is only
 // 256 waves on 1024 SIMDs, and each loop alone is issue-bound on its SIMD: splitting them uses a
 // second SIMD per 64 channels.  Same per-sample arithmetic as psk_loops_kernel.
-constexpr int SPLIT_KB = 16;
+// samples per ring block.  Measured on 2^14 channels x 1024 matched-filter samples (loops alone): 8 0.258 ms, 16 0.215,
+// 24 0.204, 32 0.2015, 64 0.282 (one barrier per block; the carrier loop starts one block late)
+#ifndef SDRX_SPLIT_KB
+#define SDRX_SPLIT_KB 32
+#endif
+constexpr int SPLIT_KB = SDRX_SPLIT_KB;
 
 template <int KIND>
 __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__restrict__ mf, size_t m, size_t nchan,
