@@ -377,7 +377,9 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
     if (blocks > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
     // few channels (fewer waves than SIMDs): give each 64-channel group a second SIMD
     const int split_env = tuning().psk_split; // 0 / 1 force one form (tests, experiments)
-    const bool split = split_env >= 0 ? split_env != 0 : blocks <= 2048;
+    // (the two-wave form holds 64 KB of LDS per workgroup: two per CU, 512 at a time; measured, loops alone, two-wave /
+    // one-wave: 2^15 channels 0.125 / 0.181 ms, 2^16 0.128 / 0.119, 2^17 0.146 / 0.115)
+    const bool split = split_env >= 0 ? split_env != 0 : blocks <= 512;
     if (run_timing && run_phase && split) {
         if (kind == SDRX_BPSK)
             hipLaunchKernelGGL(psk_loops_split_kernel<SDRX_BPSK>, dim3((unsigned)blocks), dim3(128), 0, s,
