@@ -150,37 +150,58 @@ __device__ __forceinline__ SatMap sat_then(const SatMap &g1, const SatMap &g2) /
 constexpr int OZC_WAVES = 16;
 
 // STREAM: nontemporal loads (a bank of streams: 0.87 vs 0.92 ms for 512 x 2^19; a single stream is slower with them)
-template <bool STREAM>
+// WIDE: 16-byte loads, two samples per lane (rows 16-byte aligned): a wave's 64 loads cover 8192 samples; the two
+// decisions of a load are two ballot masks (even and odd samples), parked together in lane j, which walks its 128
+// samples as E bit 0, O bit 0, E bit 1, ...
+template <bool STREAM, bool WIDE>
 __global__ void __launch_bounds__(64 * OZC_WAVES) ones_zeros_confidence_kernel(const double *__restrict__ re_all,
                                                                                 const double *__restrict__ im_all, size_t n,
                                                                                 size_t pitch, double thr2, int32_t cmax,
                                                                                 int32_t *__restrict__ counters)
 {
     __shared__ SatMap part[OZC_WAVES];
+    constexpr size_t PER_LANE = WIDE ? 128 : 64, PER_WAVE = 64 * PER_LANE;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double *re = re_all + (size_t)blockIdx.x * pitch, *im = im_all + (size_t)blockIdx.x * pitch;
     SatMap run = {0, -SAT_INF, SAT_INF}; // (thread 0) the walk so far
-    for (size_t base = 0; base < n; base += 4096 * OZC_WAVES) {
-        const size_t wbase = base + (size_t)wave * 4096;
-        unsigned long long mine = 0;
+    for (size_t base = 0; base < n; base += PER_WAVE * OZC_WAVES) {
+        const size_t wbase = base + (size_t)wave * PER_WAVE;
+        unsigned long long mine = 0, mine_odd = 0;
 #pragma unroll 8
         for (int j = 0; j < 64; j++) {
-            const size_t i = wbase + 64 * (size_t)j + lane;
-            bool one = false;
-            if (i < n) {
-                const double a = STREAM ? __builtin_nontemporal_load(re + i) : re[i];
-                const double b = STREAM ? __builtin_nontemporal_load(im + i) : im[i];
-                one = (a * a + b * b) >= thr2; // rtlsdr_receiver.cpp:2066 (sqrt folded into thr2)
+            if constexpr (WIDE) {
+                const size_t i = wbase + 128 * (size_t)j + 2 * (size_t)lane;
+                bool one0 = false, one1 = false;
+                if (i + 1 < n) {
+                    const v2d a = STREAM ? __builtin_nontemporal_load((const v2d *)(re + i)) : *(const v2d *)(re + i);
+                    const v2d b = STREAM ? __builtin_nontemporal_load((const v2d *)(im + i)) : *(const v2d *)(im + i);
+                    one0 = (a.x * a.x + b.x * b.x) >= thr2; // rtlsdr_receiver.cpp:2066 (sqrt folded into thr2)
+                    one1 = (a.y * a.y + b.y * b.y) >= thr2;
+                } else if (i < n) {
+                    const double a = re[i], b = im[i];
+                    one0 = (a * a + b * b) >= thr2;
+                }
+                const unsigned long long m0 = __ballot(one0), m1 = __ballot(one1);
+                if (lane == (unsigned)j) { mine = m0; mine_odd = m1; }
+            } else {
+                const size_t i = wbase + 64 * (size_t)j + lane;
+                bool one = false;
+                if (i < n) {
+                    const double a = STREAM ? __builtin_nontemporal_load(re + i) : re[i];
+                    const double b = STREAM ? __builtin_nontemporal_load(im + i) : im[i];
+                    one = (a * a + b * b) >= thr2; // rtlsdr_receiver.cpp:2066 (sqrt folded into thr2)
+                }
+                const unsigned long long m = __ballot(one);
+                if (lane == (unsigned)j) mine = m;
             }
-            const unsigned long long m = __ballot(one);
-            if (lane == (unsigned)j) mine = m;
         }
-        // this lane's run: samples wbase + 64 lane + [0, cnt)
-        const size_t seg = wbase + 64 * (size_t)lane;
-        const int cnt = seg >= n ? 0 : (n - seg < 64 ? (int)(n - seg) : 64);
+        // this lane's run: samples wbase + PER_LANE lane + [0, cnt)
+        const size_t seg = wbase + PER_LANE * (size_t)lane;
+        const int cnt = seg >= n ? 0 : (n - seg < PER_LANE ? (int)(n - seg) : (int)PER_LANE);
         SatMap g = {0, -SAT_INF, SAT_INF};
         for (int b = 0; b < cnt; b++) {
-            const long long a = ((mine >> b) & 1ull) ? 1 : -1;
+            const unsigned long long bits = WIDE ? ((b & 1) ? mine_odd : mine) : mine;
+            const long long a = ((bits >> (WIDE ? (b >> 1) : b)) & 1ull) ? 1 : -1;
             g.A += a;
             g.L = clampll(g.L + a, 0, cmax);
             g.H = clampll(g.H + a, 0, cmax);
@@ -212,12 +233,16 @@ int launch_ones_zeros_confidence(const double *re, const double *im, size_t n, s
         return SDRX_EINVAL;
     }
     if (nchan > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
-    if (nchan >= 64)
-        hipLaunchKernelGGL(ones_zeros_confidence_kernel<true>, dim3((unsigned)nchan), dim3(64 * OZC_WAVES), 0, s, re, im, n,
-                           pitch, am_threshold_sq(), cmax, counters);
-    else
-        hipLaunchKernelGGL(ones_zeros_confidence_kernel<false>, dim3((unsigned)nchan), dim3(64 * OZC_WAVES), 0, s, re, im, n,
-                           pitch, am_threshold_sq(), cmax, counters);
+    const bool wide = ((((size_t)re) | ((size_t)im)) & 15) == 0 && (nchan == 1 || pitch % 2 == 0);
+    const dim3 grid((unsigned)nchan), wg(64 * OZC_WAVES);
+    const double thr2 = am_threshold_sq();
+    if (nchan >= 64) {
+        if (wide) hipLaunchKernelGGL((ones_zeros_confidence_kernel<true, true>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters);
+        else hipLaunchKernelGGL((ones_zeros_confidence_kernel<true, false>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters);
+    } else {
+        if (wide) hipLaunchKernelGGL((ones_zeros_confidence_kernel<false, true>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters);
+        else hipLaunchKernelGGL((ones_zeros_confidence_kernel<false, false>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters);
+    }
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }
