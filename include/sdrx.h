@@ -153,7 +153,10 @@ int sdrx_ones_zeros_dev(const double *re, const double *im, size_t n, int32_t *c
 /* The same branch as the reference's CPU path runs it (rtlsdr_receiver.cpp:2063-2074): a confidence_counter walked
  * by increment(1) / decrement(1) per sample, clamped to [0, max] after every step (confidence_counter.h:50-72); nchan
  * independent streams (rows at `pitch`), counters[c] (device int32) read and written.  The walk is an ordered
- * reduction of clamp maps: exact, whatever the rails do. */
+ * reduction of clamp maps: exact, whatever the rails do.  With fewer than 256 streams of >= 262144 samples the streams
+ * are cut into segments that share one per-GPU array of maps; the library orders such calls on the GPU with an event
+ * (a later call waits for the earlier one's last kernel, whichever streams they are on), and runs the one-workgroup
+ * form while `stream` is being captured. */
 int sdrx_ones_zeros_confidence_dev(const double *re, const double *im, size_t n, size_t nchan, size_t pitch, int32_t max,
                                    int32_t *counters, void *stream);
 /* FM<T>::demodulate (FM.h:83-148, repaired): w1/w2 device tables of ds doubles; out[n/ds] bits */

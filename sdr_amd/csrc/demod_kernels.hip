@@ -5,6 +5,8 @@
 //                        ones_zeros.cu:28-52 was meant to compute
 //   fsk_corr_kernel    : FM<T>::demodulate (FM.h:83-148 with the SURVEY section 8c repair)
 #include "sdrx_internal.h"
+#include <map>
+#include <mutex>
 
 #include "../../include/sdrx_math.h"
 
@@ -153,18 +155,27 @@ constexpr int OZC_WAVES = 16;
 // WIDE: 16-byte loads, two samples per lane (rows 16-byte aligned): a wave's 64 loads cover 8192 samples; the two
 // decisions of a load are two ballot masks (even and odd samples), parked together in lane j, which walks its 128
 // samples as E bit 0, O bit 0, E bit 1, ...
+// seg_len != 0: a stream is cut into gridDim.y segments, one workgroup each; a segment's composed map goes to
+// oz_parts[channel * gridDim.y + segment] (a file-scope device array: one per GPU) and ones_zeros_fold_kernel applies the
+// segments' maps in order -- for a few long streams (one radio's block), where one workgroup per stream leaves the chip
+// idle.  Calls that use the array are ordered on the GPU by an event (launch_ones_zeros_confidence).
+constexpr unsigned OZC_MAX_PARTS = 16384, OZC_MAX_SEGS = 64;
+static __device__ SatMap oz_parts[OZC_MAX_PARTS];
+
 template <bool STREAM, bool WIDE>
 __global__ void __launch_bounds__(64 * OZC_WAVES) ones_zeros_confidence_kernel(const double *__restrict__ re_all,
-                                                                                const double *__restrict__ im_all, size_t n,
+                                                                                const double *__restrict__ im_all, size_t n_all,
                                                                                 size_t pitch, double thr2, int32_t cmax,
-                                                                                int32_t *__restrict__ counters)
+                                                                                int32_t *__restrict__ counters, size_t seg_len)
 {
     __shared__ SatMap part[OZC_WAVES];
     constexpr size_t PER_LANE = WIDE ? 128 : 64, PER_WAVE = 64 * PER_LANE;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double *re = re_all + (size_t)blockIdx.x * pitch, *im = im_all + (size_t)blockIdx.x * pitch;
+    const size_t first = seg_len ? (size_t)blockIdx.y * seg_len : 0;
+    const size_t n = seg_len ? (first + seg_len < n_all ? first + seg_len : n_all) : n_all; // end of this workgroup's samples
     SatMap run = {0, -SAT_INF, SAT_INF}; // (thread 0) the walk so far
-    for (size_t base = 0; base < n; base += PER_WAVE * OZC_WAVES) {
+    for (size_t base = first; base < n; base += PER_WAVE * OZC_WAVES) {
         const size_t wbase = base + (size_t)wave * PER_WAVE;
         unsigned long long mine = 0, mine_odd = 0;
 #pragma unroll 8
@@ -218,11 +229,39 @@ __global__ void __launch_bounds__(64 * OZC_WAVES) ones_zeros_confidence_kernel(c
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        long long x = counters[blockIdx.x];
-        x = clampll(x + run.A, run.L, run.H);
-        counters[blockIdx.x] = (int32_t)x;
+        if (seg_len) {
+            oz_parts[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = run;
+        } else {
+            long long x = counters[blockIdx.x];
+            x = clampll(x + run.A, run.L, run.H);
+            counters[blockIdx.x] = (int32_t)x;
+        }
     }
 }
+
+// one wave per stream: the segments' maps in order, then the carried counter through the composed map
+__global__ void __launch_bounds__(64) ones_zeros_fold_kernel(int32_t *__restrict__ counters, unsigned segs)
+{
+    const unsigned lane = threadIdx.x;
+    SatMap g = {0, -SAT_INF, SAT_INF};
+    if (lane < segs) g = oz_parts[(size_t)blockIdx.x * segs + lane];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { // lane i (earlier) absorbs lane i + off (later); identity maps beyond segs
+        SatMap o = {__shfl_down(g.A, off), __shfl_down(g.L, off), __shfl_down(g.H, off)};
+        if (lane + off < 64) g = sat_then(g, o);
+    }
+    if (lane == 0) {
+        long long x = counters[blockIdx.x];
+        counters[blockIdx.x] = (int32_t)clampll(x + g.A, g.L, g.H);
+    }
+}
+
+struct OzOrder { // the last call that used oz_parts on a device: the next one waits for it on the GPU
+    hipEvent_t ev = nullptr;
+    bool used = false;
+};
+static std::mutex g_oz_mu;
+static std::map<int, OzOrder> g_oz;
 
 int launch_ones_zeros_confidence(const double *re, const double *im, size_t n, size_t nchan, size_t pitch, int32_t cmax,
                                  int32_t *counters, hipStream_t s)
@@ -234,16 +273,51 @@ int launch_ones_zeros_confidence(const double *re, const double *im, size_t n, s
     }
     if (nchan > 0x7fffffffULL) return SDRX_EUNSUPPORTED;
     const bool wide = ((((size_t)re) | ((size_t)im)) & 15) == 0 && (nchan == 1 || pitch % 2 == 0);
-    const dim3 grid((unsigned)nchan), wg(64 * OZC_WAVES);
+    const dim3 wg(64 * OZC_WAVES);
     const double thr2 = am_threshold_sq();
-    if (nchan >= 64) {
-        if (wide) hipLaunchKernelGGL((ones_zeros_confidence_kernel<true, true>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters);
-        else hipLaunchKernelGGL((ones_zeros_confidence_kernel<true, false>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters);
-    } else {
-        if (wide) hipLaunchKernelGGL((ones_zeros_confidence_kernel<false, true>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters);
-        else hipLaunchKernelGGL((ones_zeros_confidence_kernel<false, false>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters);
+    // few long streams: segments of >= one workgroup pass (131072 samples) each, about 1024 workgroups in all
+    const size_t pass = (size_t)8192 * OZC_WAVES;
+    size_t segs = 1;
+    if (nchan < 256 && n >= 2 * pass) {
+        segs = (n + pass - 1) / pass;
+        const size_t want = 1024 / nchan;
+        if (segs > want) segs = want;
+        if (segs > OZC_MAX_SEGS) segs = OZC_MAX_SEGS;
+        if (segs * nchan > OZC_MAX_PARTS) segs = 1;
     }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (segs > 1 && (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) segs = 1; // (events)
+    size_t seg_len = 0;
+    if (segs > 1) {
+        seg_len = ((n + segs - 1) / segs + 8191) & ~(size_t)8191;
+        segs = (n + seg_len - 1) / seg_len;
+    }
+    const dim3 grid((unsigned)nchan, (unsigned)segs);
+    auto launch = [&]() {
+        if (nchan >= 64) {
+            if (wide) hipLaunchKernelGGL((ones_zeros_confidence_kernel<true, true>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters, seg_len);
+            else hipLaunchKernelGGL((ones_zeros_confidence_kernel<true, false>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters, seg_len);
+        } else {
+            if (wide) hipLaunchKernelGGL((ones_zeros_confidence_kernel<false, true>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters, seg_len);
+            else hipLaunchKernelGGL((ones_zeros_confidence_kernel<false, false>), grid, wg, 0, s, re, im, n, pitch, thr2, cmax, counters, seg_len);
+        }
+    };
+    if (segs <= 1) {
+        launch();
+        SDRX_HIP(hipGetLastError());
+        return SDRX_OK;
+    }
+    int dev = 0;
+    SDRX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_oz_mu);
+    OzOrder &o = g_oz[dev];
+    if (!o.ev) SDRX_HIP(hipEventCreateWithFlags(&o.ev, hipEventDisableTiming));
+    if (o.used) SDRX_HIP(hipStreamWaitEvent(s, o.ev, 0)); // the previous user of oz_parts on this GPU has finished
+    launch();
+    hipLaunchKernelGGL(ones_zeros_fold_kernel, dim3((unsigned)nchan), dim3(64), 0, s, counters, (unsigned)segs);
     SDRX_HIP(hipGetLastError());
+    SDRX_HIP(hipEventRecord(o.ev, s));
+    o.used = true;
     return SDRX_OK;
 }
 

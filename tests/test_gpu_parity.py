@@ -485,6 +485,35 @@ def test_ones_zeros_confidence_walk(n):
     assert cnt.cpu().tolist() == want
 
 
+@pytest.mark.parametrize("nchan,n", [(1, 262144), (1, 262145), (1, 1200000), (1, 9000001), (3, 300001), (20, 524288 + 77),
+                                     (255, 262144 + 8191), (256, 262144)])
+def test_ones_zeros_confidence_walk_in_segments(nchan, n):
+    """A few long streams (one radio's block): the walk is cut into segments, one workgroup each, whose maps a second
+    kernel applies in order.  Small maxima (the rails are hit inside every segment), one like the receiver's, and two
+    calls in a row on two streams (they share the per-GPU array of maps): counters equal the literal loop's."""
+    rng = np.random.default_rng(nchan * 31 + n)
+    mag = np.where(rng.random((nchan, n)) < rng.random((nchan, 1)), 100.0, 10.0)
+    ph = rng.integers(0, 4, (nchan, n)) * (np.pi / 2)
+    re, im = np.round(mag * np.cos(ph)), np.round(mag * np.sin(ph))
+    re_d, im_d = _rows_dev(re), _rows_dev(im)
+    side = torch.cuda.Stream()
+    for cmax in (5, 500000):
+        start = rng.integers(0, cmax + 1, nchan).astype(np.int32)
+        cnt = torch.tensor(start, device="cuda")
+        cnt2 = torch.tensor(start[::-1].copy(), device="cuda")
+        torch.cuda.synchronize()
+        device.ones_zeros_confidence(re_d, im_d, cmax, cnt)
+        with torch.cuda.stream(side):
+            device.ones_zeros_confidence(re_d, im_d, cmax, cnt2)
+        torch.cuda.synchronize()
+        want = [L.orc_ones_zeros_confidence(np.ascontiguousarray(re[c]), np.ascontiguousarray(im[c]), n, cmax, int(start[c]))
+                for c in range(nchan)]
+        want2 = [L.orc_ones_zeros_confidence(np.ascontiguousarray(re[c]), np.ascontiguousarray(im[c]), n, cmax, int(start[::-1][c]))
+                 for c in range(nchan)]
+        assert cnt.cpu().tolist() == want
+        assert cnt2.cpu().tolist() == want2
+
+
 # =============================================================================== DSP primitives (SURVEY 8f rank 3)
 
 @pytest.mark.parametrize("cw", [4, 16, 64])
