@@ -696,55 +696,63 @@ __global__ void __launch_bounds__(256) rtlfm_post_kernel(int16_t *__restrict__ p
     if (deemph_a > 0) { // the workgroup moves the row through LDS in chunks; one lane runs the recurrence there
         int avg = ps[0];
         const int half = deemph_a / 2;
-        // q = (u * magic) >> 32 == u / a exactly for u < 2^20, a < 2^11 (sdrx_internal.h: magic_u32)
-        const unsigned magic = deemph_a < 2048 ? (unsigned)((0x100000000ULL + (unsigned)deemph_a - 1) / (unsigned)deemph_a) : 0u;
+        // which wave runs the recurrence: a SIMD issues one scalar instruction per turn whichever of its waves it is
+        // from, so the serial waves of the workgroups that share a CU should sit on different SIMDs
+        const unsigned serial_wave = blockIdx.x & 3;
+        // q = (x * magic) >> 32 (signed) == floor(x / a) for |x| < 2^20, 3 <= a < 2^11: magic < 2^31 and x * (magic * a - 2^32) < 2^32
+        const unsigned magic = deemph_a >= 3 && deemph_a < 2048 ? (unsigned)((0x100000000ULL + (unsigned)deemph_a - 1) / (unsigned)deemph_a) : 0u;
         for (int i0 = 0; i0 < len; i0 += DEEMPH_CHUNK) {
             const int cn = len - i0 < DEEMPH_CHUNK ? len - i0 : DEEMPH_CHUNK;
             for (int i = (int)tid; i < cn; i += 256) stage[i] = res[i0 + i];
             __syncthreads();
-            if (tid == 0) {
-                // 8 samples per 16-byte LDS access; the next block is read before the current block's chain runs
+            if ((tid >> 6) == serial_wave) {
+                // The recurrence is one chain of 32-bit integer operations: every lane of the first wave holds the same
+                // values (readfirstlane), so the chain runs on the scalar unit -- one result per cycle or two instead
+                // of a vector instruction's four-cycle issue -- and lane 0 stores.  8 samples per 16-byte LDS access;
+                // the next block is read before the current block's chain runs.
                 uint4 *blk = reinterpret_cast<uint4 *>(stage);
                 const int nblk = (cn + 7) / 8;
+                int av = __builtin_amdgcn_readfirstlane(avg);
                 uint4 nxt = blk[0];
                 for (int b = 0; b < nblk; b++) {
-                    uint4 cur = nxt;
+                    const uint4 cur = nxt;
                     if (b + 1 < nblk) nxt = blk[b + 1];
-                    unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+                    unsigned w[4] = {(unsigned)__builtin_amdgcn_readfirstlane((int)cur.x), (unsigned)__builtin_amdgcn_readfirstlane((int)cur.y),
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)cur.z), (unsigned)__builtin_amdgcn_readfirstlane((int)cur.w)};
                     const int lim = cn - 8 * b < 8 ? cn - 8 * b : 8;
                     // avg never leaves the range of the int16 inputs once inside it (|step| <= |d|), so there
                     // |d +- a/2| < 2^20 and the magic multiply is the exact quotient; otherwise divide
-                    if (magic && (unsigned)(avg + 32768) < 65536u) {
+                    if (magic && (unsigned)(av + 32768) < 65536u) {
+                        // x = d +- a/2 with the sign of d; trunc(x / a) = mulhi(x, magic) for x >= 0 and mulhi(x, magic) + 1
+                        // for x < 0 (the product lies less than 1/a below x / a).  A short last block runs all 8 steps
+                        // and takes the avg of its last real sample back out of the packed results (int16 range).
 #pragma unroll
                         for (int k = 0; k < 8; k++) {
-                            if (k < lim) {
-                                const int v = (int)(int16_t)(w[k >> 1] >> (16 * (k & 1)));
-                                const int d = v - avg; // both signs' quotients side by side: a shorter dependent chain
-                                const int qp = (int)__umulhi((unsigned)(d + half), magic);  // d > 0: (d + a/2) / a
-                                const int qn = (int)__umulhi((unsigned)(half - d), magic);  // d <= 0: -((a/2 - d) / a), C division
-                                avg += d > 0 ? qp : -qn;                                     // truncates towards zero
-                                w[k >> 1] = (w[k >> 1] & ~(0xffffu << (16 * (k & 1)))) | (((unsigned)avg & 0xffffu) << (16 * (k & 1)));
-                            }
+                            const int v = (int)(int16_t)(w[k >> 1] >> (16 * (k & 1)));
+                            const bool pos = v > av; // d > 0
+                            const int x = (v - av) + (pos ? half : -half);
+                            av = (pos ? av : av + 1) + __mulhi(x, (int)magic);
+                            w[k >> 1] = (w[k >> 1] & ~(0xffffu << (16 * (k & 1)))) | (((unsigned)av & 0xffffu) << (16 * (k & 1)));
                         }
+                        if (lim < 8) av = (int)(int16_t)(w[(lim - 1) >> 1] >> (16 * ((lim - 1) & 1)));
                     } else {
 #pragma unroll
                         for (int k = 0; k < 8; k++) { // (unrolled: w[] must stay in registers)
-                            if (k < lim) {
-                                const int v = (int)(int16_t)(w[k >> 1] >> (16 * (k & 1)));
-                                const int d = v - avg;
-                                avg += (d > 0 ? d + half : d - half) / deemph_a;
-                                w[k >> 1] = (w[k >> 1] & ~(0xffffu << (16 * (k & 1)))) | (((unsigned)avg & 0xffffu) << (16 * (k & 1)));
-                            }
+                            const int v = (int)(int16_t)(w[k >> 1] >> (16 * (k & 1)));
+                            const int d = v - av;
+                            av += k < lim ? (d > 0 ? d + half : d - half) / deemph_a : 0;
+                            w[k >> 1] = (w[k >> 1] & ~(0xffffu << (16 * (k & 1)))) | (((unsigned)av & 0xffffu) << (16 * (k & 1)));
                         }
                     }
-                    blk[b] = make_uint4(w[0], w[1], w[2], w[3]);
+                    if ((tid & 63) == 0) blk[b] = make_uint4(w[0], w[1], w[2], w[3]);
                 }
+                avg = av;
             }
             __syncthreads();
             for (int i = (int)tid; i < cn; i += 256) res[i0 + i] = stage[i];
             __syncthreads();
         }
-        if (tid == 0) ps[0] = avg;
+        if (tid == 64 * serial_wave) ps[0] = avg;
         __syncthreads();
     }
     if (dc_block && len > 0) {

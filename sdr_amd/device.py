@@ -19,6 +19,12 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _need(cond, what):
+    """The kernels trust the shapes they are given (a wrong one is an out-of-bounds access on the GPU): checked here."""
+    if not cond:
+        raise ValueError("sdr_amd.device: " + what)
+
+
 def init(device_index=0):
     _lib.check(_lib.lib().sdrx_init(int(device_index)), "sdrx_init")
 
@@ -84,27 +90,41 @@ class FirChain:
         if isinstance(x, (tuple, list)):
             re, im = x
             assert re.dtype == self.dtype == im.dtype and re.is_contiguous() and im.is_contiguous()
+            _need(re.shape == im.shape and re.numel() == self.nchan * re.shape[-1], "re / im must be (nchan, n)")
             return _lib.IQ_SPLIT, re, im, re.shape[-1], re.shape[-1]
         if x.dtype == torch.uint8:  # (nchan, n, 2) raw radio bytes
             assert x.is_contiguous() and x.dim() == 3 and x.shape[-1] == 2
+            _need(x.shape[0] == self.nchan, "input must have nchan rows")
             return _lib.IQ_U8, x, None, x.shape[1], x.shape[1]
         assert x.dtype == self.dtype and x.is_contiguous()
         if x.dim() == 3 and x.shape[-1] == 2:
+            _need(x.shape[0] == self.nchan, "input must have nchan rows")
             return _lib.IQ_INTERLEAVED, x, None, x.shape[1], x.shape[1]
+        _need(x.numel() == self.nchan * x.shape[-1], "input must be (nchan, n)")
         return _lib.REAL, x, None, x.shape[-1], x.shape[-1]
+
+    def _outputs(self, n, n_out, *outs):
+        want = int(n_out) if n_out else self.n_out(n)
+        for o in outs:
+            if o is not None:
+                _need(o.is_contiguous() and o.dim() >= 2 and o.shape[0] == self.nchan and o.shape[1] >= want,
+                      "output must be (nchan, >= %d) and contiguous" % want)
 
     def fir(self, x, out0, out1=None, fast_fma=False, n_out=0):
         layout, in0, in1, n, pitch = self._inputs(x)
+        self._outputs(n, n_out, out0, out1)
         op = out0.shape[1]
         self._run(self.L.sdrx_fir_dev, "sdrx_fir_dev", layout, in0, in1, n, pitch, out0, out1, op, fast_fma, n_out)
 
     def fir_am(self, x, bits, fast_fma=False):
         layout, in0, in1, n, pitch = self._inputs(x)
+        self._outputs(n, 0, bits)
         self._run(self.L.sdrx_fir_am_dev, "sdrx_fir_am_dev", layout, in0, in1, n, pitch, bits, None, bits.shape[1],
                   fast_fma)
 
     def fir_fmdisc(self, x, angle, fast_fma=False):
         layout, in0, in1, n, pitch = self._inputs(x)
+        self._outputs(n, 0, angle)
         self._run(self.L.sdrx_fir_fmdisc_dev, "sdrx_fir_fmdisc_dev", layout, in0, in1, n, pitch, angle, None,
                   angle.shape[1], fast_fma)
 
@@ -144,11 +164,13 @@ class FirRing:
 
 
 def am_demod(re, im, out, ds):
+    _need(im.numel() == re.numel() and int(ds) >= 1 and out.numel() >= (re.numel() + int(ds) - 1) // int(ds), "am_demod: sizes")
     _lib.check(_lib.lib().sdrx_am_demod_dev(_ptr(re), _ptr(im), _ptr(out), re.numel(), int(ds), _stream()),
                "sdrx_am_demod_dev")
 
 
 def ones_zeros(re, im, count):
+    _need(im.numel() == re.numel() and count.numel() >= 1, "ones_zeros: sizes")
     _lib.check(_lib.lib().sdrx_ones_zeros_dev(_ptr(re), _ptr(im), re.numel(), _ptr(count), _stream()),
                "sdrx_ones_zeros_dev")
 
@@ -165,6 +187,7 @@ def ones_zeros_confidence(re, im, cmax, counters):
 
 
 def fm_demod(re, w1, w2, out, ds):
+    _need(int(ds) >= 1 and w1.numel() >= int(ds) and w2.numel() >= int(ds) and out.numel() >= re.numel() // int(ds), "fm_demod: sizes")
     _lib.check(_lib.lib().sdrx_fm_demod_dev(_ptr(re), _ptr(w1), _ptr(w2), _ptr(out), re.numel(), int(ds), _stream()),
                "sdrx_fm_demod_dev")
 
@@ -219,8 +242,11 @@ class RtlFm:
 
     def demod(self, raw, pcm):
         """raw: (nchan, n, 2) uint8; pcm: (nchan, >= (prev_index + n) // downsample) int16.  Returns the count."""
-        assert raw.dtype == torch.uint8 and raw.is_contiguous() and pcm.dtype == torch.int16
+        assert raw.dtype == torch.uint8 and raw.is_contiguous() and pcm.dtype == torch.int16 and pcm.is_contiguous()
         n = raw.shape[1]
+        _need(raw.dim() == 3 and raw.shape[0] == self.nchan and raw.shape[2] == 2, "raw must be (nchan, n, 2)")
+        _need(pcm.dim() == 2 and pcm.shape[0] == self.nchan and pcm.shape[1] >= (self.prev_index + n) // self.ds,
+              "pcm must be (nchan, >= (prev_index + n) // downsample)")
         _lib.check(self.L.sdrx_rtlfm_dev(_ptr(raw), n, self.nchan, n, self.ds, int(self.rot), _ptr(self.state[self.cur]),
                                          _ptr(self.state[self.cur ^ 1]), _ptr(pcm), pcm.shape[1], _stream()),
                    "sdrx_rtlfm_dev")
@@ -246,6 +272,9 @@ class RtlFmFull(RtlFm):
         """As RtlFm.demod; returns result_len (the same for every channel)."""
         assert raw.dtype == torch.uint8 and raw.is_contiguous() and pcm.dtype == torch.int16 and pcm.is_contiguous()
         n = raw.shape[1]
+        _need(raw.dim() == 3 and raw.shape[0] == self.nchan and raw.shape[2] == 2, "raw must be (nchan, n, 2)")
+        _need(pcm.dim() == 2 and pcm.shape[0] == self.nchan and pcm.shape[1] >= (self.prev_index + n) // self.ds,
+              "pcm must be (nchan, >= (prev_index + n) // downsample)")
         _lib.check(self.L.sdrx_rtlfm_full_dev(C.byref(self.params), _ptr(raw), n, self.nchan, n, _ptr(self.state[self.cur]),
                                               _ptr(self.state[self.cur ^ 1]), _ptr(self.post_state), _ptr(self.work),
                                               _ptr(pcm), pcm.shape[1], _stream()), "sdrx_rtlfm_full_dev")
@@ -384,6 +413,9 @@ class PskBank:
     def demod(self, iq, out):
         """iq: (nchan, n, 2) f64; out: (nchan, >= n/8) uint8."""
         assert iq.dtype == torch.float64 and iq.is_contiguous() and iq.shape[1] == self.n
+        _need(iq.shape[0] == self.nchan and iq.numel() == self.nchan * self.n * 2, "iq must be (nchan, n, 2)")
+        _need(out.dtype == torch.uint8 and out.is_contiguous() and out.shape[0] == self.nchan and out.shape[1] >= self.n_dec,
+              "out must be (nchan, >= n_dec) uint8")
         _lib.check(self.L.sdrx_psk_demod_dev(self.kind, _ptr(iq), self.n, self.nchan, self.n, _ptr(self.states),
                                              _ptr(out), out.shape[1], _ptr(self.work), _stream()),
                    "sdrx_psk_demod_dev")
