@@ -5,6 +5,7 @@
 //                        ones_zeros.cu:28-52 was meant to compute
 //   fsk_corr_kernel    : FM<T>::demodulate (FM.h:83-148 with the SURVEY section 8c repair)
 #include "sdrx_internal.h"
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -674,13 +675,13 @@ __global__ void __launch_bounds__(256) rtlfm_post_kernel(int16_t *__restrict__ p
     __shared__ long long red[4];
     __shared__ __align__(16) int16_t stage[DEEMPH_CHUNK];
     const size_t chan = blockIdx.x;
-    const unsigned tid = threadIdx.x;
+    const unsigned tid = threadIdx.x, nt = blockDim.x; // 256, or 64 when the serial de-emphasis sets the pace
     int16_t *res = pcm_all + chan * out_pitch;
     int32_t *ps = post_state + 4 * chan;
     int len = (int)(((long long)st_in[5 * chan + 2] + (long long)n) / ds); // result_len after fm_demod
     if (step > 1) {
         const int W = (len + step - 1) / step;
-        for (int k0 = 0; k0 < W; k0 += 256) { // output k lands below every value a later window reads
+        for (int k0 = 0; k0 < W; k0 += nt) { // output k lands below every value a later window reads
             const int k = k0 + (int)tid;
             int sum = 0;
             if (k < W)
@@ -698,12 +699,12 @@ __global__ void __launch_bounds__(256) rtlfm_post_kernel(int16_t *__restrict__ p
         const int half = deemph_a / 2;
         // which wave runs the recurrence: a SIMD issues one scalar instruction per turn whichever of its waves it is
         // from, so the serial waves of the workgroups that share a CU should sit on different SIMDs
-        const unsigned serial_wave = blockIdx.x & 3;
+        const unsigned serial_wave = blockIdx.x & (nt / 64 - 1);
         // q = (x * magic) >> 32 (signed) == floor(x / a) for |x| < 2^20, 3 <= a < 2^11: magic < 2^31 and x * (magic * a - 2^32) < 2^32
         const unsigned magic = deemph_a >= 3 && deemph_a < 2048 ? (unsigned)((0x100000000ULL + (unsigned)deemph_a - 1) / (unsigned)deemph_a) : 0u;
         for (int i0 = 0; i0 < len; i0 += DEEMPH_CHUNK) {
             const int cn = len - i0 < DEEMPH_CHUNK ? len - i0 : DEEMPH_CHUNK;
-            for (int i = (int)tid; i < cn; i += 256) stage[i] = res[i0 + i];
+            for (int i = (int)tid; i < cn; i += nt) stage[i] = res[i0 + i];
             __syncthreads();
             if ((tid >> 6) == serial_wave) {
                 // The recurrence is one chain of 32-bit integer operations: every lane of the first wave holds the same
@@ -749,7 +750,7 @@ __global__ void __launch_bounds__(256) rtlfm_post_kernel(int16_t *__restrict__ p
                 avg = av;
             }
             __syncthreads();
-            for (int i = (int)tid; i < cn; i += 256) res[i0 + i] = stage[i];
+            for (int i = (int)tid; i < cn; i += nt) res[i0 + i] = stage[i];
             __syncthreads();
         }
         if (tid == 64 * serial_wave) ps[0] = avg;
@@ -757,16 +758,17 @@ __global__ void __launch_bounds__(256) rtlfm_post_kernel(int16_t *__restrict__ p
     }
     if (dc_block && len > 0) {
         long long sum = 0;
-        for (int i = (int)tid; i < len; i += 256) sum += res[i];
+        for (int i = (int)tid; i < len; i += nt) sum += res[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
         if ((tid & 63) == 0) red[tid >> 6] = sum;
         __syncthreads();
-        sum = red[0] + red[1] + red[2] + red[3];
+        sum = red[0];
+        for (unsigned w2 = 1; w2 < nt / 64; w2++) sum += red[w2];
         int avg = (int)(sum / len);
         avg = (avg + ps[1] * 9) / 10;
         __syncthreads(); // every thread has read ps[1]
-        for (int i = (int)tid; i < len; i += 256) res[i] = (int16_t)((int)res[i] - avg);
+        for (int i = (int)tid; i < len; i += nt) res[i] = (int16_t)((int)res[i] - avg);
         if (tid == 0) ps[1] = avg;
     }
     if (tid == 0) ps[3] = len;

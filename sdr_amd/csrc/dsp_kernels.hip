@@ -223,45 +223,90 @@ __device__ __forceinline__ double fifth_out(Pair ab, Pair cd, Pair ef)
 }
 
 // BLOCK = false: the double* overload (one rail, every pass over the same n).  BLOCK = true: the BBP_Block
-// overload (:28-63): the real and the imaginary rail of interleaved complex points (one workgroup each, its own six
-// state doubles), and n_points shrinks to dst + 1 after every pass (3 if the pass had no iteration: the
+// overload (:28-63): the real and the imaginary rail of interleaved complex points (each its own six state
+// doubles; one workgroup takes both, so a point is loaded and stored whole), and n_points shrinks to dst + 1 after every pass (3 if the pass had no iteration: the
 // reference's `dst = 2` start value).
+// With E[j] = data[2j] (E[0] = the new data[0]) output k >= 3 is F over E[k-3 .. k].  A chunk of FIFTH_CHUNK outputs
+// needs the samples 2(k0-3) .. 2(k0+FIFTH_CHUNK-1): loaded as 16-byte pairs (whole lines, coalesced; the odd samples
+// are never used but share the lines), the even halves kept in LDS, one barrier per chunk (two LDS buffers).
+constexpr int FIFTH_CHUNK = 1024, FIFTH_PER = FIFTH_CHUNK / 256;
+
 template <bool BLOCK>
 __global__ __launch_bounds__(256) void fifth_kernel(double *data, size_t n, size_t pitch, size_t by, double *state)
 {
-    constexpr int STRIDE = BLOCK ? 2 : 1;
-    const size_t c = BLOCK ? blockIdx.x >> 1 : blockIdx.x, rail = BLOCK ? blockIdx.x & 1 : 0;
-    double *d = data + c * pitch * STRIDE + rail;
-    double *sp = state + c * (6 * STRIDE) + rail * 6;
-    double s[6];
-    for (int j = 0; j < 6; j++) s[j] = sp[j];
+    constexpr int STRIDE = BLOCK ? 2 : 1, RAILS = BLOCK ? 2 : 1; // BLOCK: both rails of a point travel together
+    __shared__ double ev[2][RAILS][FIFTH_CHUNK + 4]; // E[k0-3 .. k0+FIFTH_CHUNK-1] of the chunk at [0 .. FIFTH_CHUNK+2]
+    const size_t c = blockIdx.x;
+    double *d = data + c * pitch * STRIDE;
+    double *sp = state + c * (6 * RAILS);
+    // 16-byte accesses need the row's first sample on a 16-byte boundary
+    const bool vec = (reinterpret_cast<size_t>(d) & 15) == 0;
+    double s[RAILS][6];
+    for (int r = 0; r < RAILS; r++)
+        for (int j = 0; j < 6; j++) s[r][j] = sp[6 * r + j];
     size_t np = n;
+    int buf = 0;
     for (size_t dec = 2; dec <= by; dec *= 2) {
         const long K = (long)((np - 1) / 2); // iterations i = 2k < np, k = 1..K
-        const double d0n = fifth_out({s[0], s[1]}, {s[2], s[3]}, {s[4], s[5]});
-        double ns[6] = {s[0], s[1], s[2], s[3], s[4], s[5]};
-        if (K >= 1) { // the window of the last iteration, read before anything is overwritten
-            Pair p0 = fifth_pair<STRIDE>(d, K - 2, s, d0n), p1 = fifth_pair<STRIDE>(d, K - 1, s, d0n),
-                 p2 = fifth_pair<STRIDE>(d, K, s, d0n);
-            ns[0] = p0.e, ns[1] = p0.f, ns[2] = p1.e, ns[3] = p1.f, ns[4] = p2.e, ns[5] = p2.f;
+        double d0n[RAILS], ns[RAILS][6], head[RAILS];
+        const bool heads = threadIdx.x >= 1 && threadIdx.x <= 3 && (long)threadIdx.x <= K; // outputs 1 .. 3 reach into
+        for (int r = 0; r < RAILS; r++) {                                                   // the carried state
+            d0n[r] = fifth_out({s[r][0], s[r][1]}, {s[r][2], s[r][3]}, {s[r][4], s[r][5]});
+            for (int j = 0; j < 6; j++) ns[r][j] = s[r][j];
+            if (K >= 1) { // the window of the last iteration, read before anything is overwritten
+                Pair p0 = fifth_pair<STRIDE>(d + r, K - 2, s[r], d0n[r]), p1 = fifth_pair<STRIDE>(d + r, K - 1, s[r], d0n[r]),
+                     p2 = fifth_pair<STRIDE>(d + r, K, s[r], d0n[r]);
+                ns[r][0] = p0.e, ns[r][1] = p0.f, ns[r][2] = p1.e, ns[r][3] = p1.f, ns[r][4] = p2.e, ns[r][5] = p2.f;
+            }
+            head[r] = 0;
+            if (heads) {
+                const long k = threadIdx.x;
+                head[r] = fifth_out(fifth_pair<STRIDE>(d + r, k - 2, s[r], d0n[r]), fifth_pair<STRIDE>(d + r, k - 1, s[r], d0n[r]),
+                                    fifth_pair<STRIDE>(d + r, k, s[r], d0n[r]));
+            }
         }
-        __syncthreads();
-        for (long k0 = 1; k0 <= K; k0 += 256) {
-            long k = k0 + threadIdx.x;
-            double out = 0;
-            if (k <= K)
-                out = fifth_out(fifth_pair<STRIDE>(d, k - 2, s, d0n), fifth_pair<STRIDE>(d, k - 1, s, d0n),
-                                fifth_pair<STRIDE>(d, k, s, d0n));
+        __syncthreads(); // every thread has read what it needs of the row as the pass found it
+        for (long k0 = 4; k0 <= K || k0 == 4; k0 += FIFTH_CHUNK, buf ^= 1) {
+            // E[k0-3 + i], i < FIFTH_CHUNK + 3, wherever an output of this chunk needs it (k <= K reads up to E[K])
+            const long e0 = k0 - 3, need = (K - e0 + 1 < FIFTH_CHUNK + 3 ? K - e0 + 1 : FIFTH_CHUNK + 3);
+            for (long i = threadIdx.x; i < need; i += 256) {
+                const double *src = d + (size_t)(2 * (e0 + i)) * STRIDE;
+                if (BLOCK) {
+                    double2 v = vec ? *reinterpret_cast<const double2 *>(src) : make_double2(src[0], src[1]);
+                    ev[buf][0][i] = v.x, ev[buf][RAILS - 1][i] = v.y;
+                } else { // (scalar for the row's last sample when n is odd: its pair would end past the row)
+                    ev[buf][0][i] = vec && (size_t)(2 * (e0 + i)) + 1 < n ? reinterpret_cast<const double2 *>(src)->x : *src;
+                }
+            }
             __syncthreads();
-            if (k <= K) d[k * STRIDE] = out;
+            if (k0 == 4 && heads)
+                for (int r = 0; r < RAILS; r++) d[threadIdx.x * STRIDE + r] = head[r];
+#pragma unroll
+            for (int q = 0; q < FIFTH_PER; q++) {
+                const long i = threadIdx.x + 256 * q, k = k0 + i;
+                if (k <= K) { // E[k-3 .. k] = ev[i .. i+3]
+                    double o[RAILS];
+                    for (int r = 0; r < RAILS; r++) {
+                        const double e0v = ev[buf][r][i], e1v = ev[buf][r][i + 1], e2v = ev[buf][r][i + 2], e3v = ev[buf][r][i + 3];
+                        o[r] = fifth_out({e0v, e1v}, {e1v, e2v}, {e2v, e3v});
+                    }
+                    if (BLOCK && vec) *reinterpret_cast<double2 *>(d + k * STRIDE) = make_double2(o[0], o[RAILS - 1]);
+                    else
+                        for (int r = 0; r < RAILS; r++) d[k * STRIDE + r] = o[r];
+                }
+            }
+            if (k0 > K) break; // (the one pass through the loop that a short row makes for its head outputs)
         }
-        if (threadIdx.x == 0) d[0] = d0n;
-        for (int j = 0; j < 6; j++) s[j] = ns[j];
+        for (int r = 0; r < RAILS; r++) {
+            if (threadIdx.x == 0) d[r] = d0n[r];
+            for (int j = 0; j < 6; j++) s[r][j] = ns[r][j];
+        }
         if (BLOCK) np = (size_t)(K >= 1 ? K : 2) + 1;
         __syncthreads(); // the next pass reads what this one wrote
     }
     if (threadIdx.x == 0)
-        for (int j = 0; j < 6; j++) sp[j] = s[j];
+        for (int r = 0; r < RAILS; r++)
+            for (int j = 0; j < 6; j++) sp[6 * r + j] = s[r][j];
 }
 
 // ---- fft (FFT.cpp:7-28): recursive radix-2 DIT == bit-reversal + log2 N butterfly stages with the
@@ -496,8 +541,7 @@ extern "C" int sdrx_fifth_order_decimate_block_dev(double *iq, size_t n_points, 
         return SDRX_EINVAL;
     }
     if (decimate_by < 2) return SDRX_OK;
-    if (nchan > 0x3fffffffULL) return SDRX_EUNSUPPORTED;
-    fifth_kernel<true><<<(unsigned)(2 * nchan), 256, 0, (hipStream_t)stream>>>(iq, n_points, pitch, decimate_by, state12);
+    fifth_kernel<true><<<(unsigned)nchan, 256, 0, (hipStream_t)stream>>>(iq, n_points, pitch, decimate_by, state12);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }

@@ -576,7 +576,7 @@ def test_dsp_normalize_bit_exact(n, scale, prev):
 
 
 @pytest.mark.parametrize("n,by", [(1, 2), (2, 2), (3, 2), (4, 2), (5, 2), (64, 2), (513, 2), (514, 2), (515, 4), (1000, 8),
-                                  (5000, 4), (40, 1)])
+                                  (5000, 4), (40, 1), (2054, 2), (2055, 2), (8192, 2), (10001, 2), (20000, 8)])
 def test_dsp_fifth_order_decimate_bit_exact(n, by):
     """fifth_order_filter::decimate(double*): in place, log2(by) passes over the same n, state carried across two
     calls; whole row (written part and untouched tail) and the six state doubles bit-identical."""
@@ -597,7 +597,7 @@ def test_dsp_fifth_order_decimate_bit_exact(n, by):
 
 
 @pytest.mark.parametrize("n,by", [(1, 2), (2, 4), (3, 2), (5, 2), (7, 16), (64, 2), (513, 2), (515, 4), (1000, 8), (5000, 4),
-                                  (40, 1)])
+                                  (40, 1), (2055, 2), (8192, 2), (10001, 4)])
 def test_dsp_fifth_order_block_overload_bit_exact(n, by):
     """fifth_order_filter::decimate(BBP_Block*): complex points, both rails, n_points shrinking pass by pass, state
     carried across two calls; whole rows, the twelve state doubles and the returned n_points equal the oracle's."""
