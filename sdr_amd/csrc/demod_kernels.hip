@@ -700,8 +700,11 @@ __global__ void __launch_bounds__(256) rtlfm_post_kernel(int16_t *__restrict__ p
         // which wave runs the recurrence: a SIMD issues one scalar instruction per turn whichever of its waves it is
         // from, so the serial waves of the workgroups that share a CU should sit on different SIMDs
         const unsigned serial_wave = blockIdx.x & (nt / 64 - 1);
-        // q = (x * magic) >> 32 (signed) == floor(x / a) for |x| < 2^20, 3 <= a < 2^11: magic < 2^31 and x * (magic * a - 2^32) < 2^32
-        const unsigned magic = deemph_a >= 3 && deemph_a < 2048 ? (unsigned)((0x100000000ULL + (unsigned)deemph_a - 1) / (unsigned)deemph_a) : 0u;
+        // magic = floor(2^32 / a) + 1 (also for a power of two: the product must lie strictly above x / a for x > 0 and
+        // strictly below for x < 0): (x * magic) >> 32 (signed) == floor(x / a) for x >= 0, == trunc(x / a) - 1 for x < 0,
+        // given |x| < 2^20 and 3 <= a < 2^11 (magic < 2^31, |x| * (magic * a - 2^32) < 2^32); checked over the whole
+        // domain by tests/test_oracle_golden.py::test_deemph_magic_division_is_exact_on_its_whole_domain
+        const unsigned magic = deemph_a >= 3 && deemph_a < 2048 ? (unsigned)(0x100000000ULL / (unsigned)deemph_a) + 1u : 0u;
         for (int i0 = 0; i0 < len; i0 += DEEMPH_CHUNK) {
             const int cn = len - i0 < DEEMPH_CHUNK ? len - i0 : DEEMPH_CHUNK;
             for (int i = (int)tid; i < cn; i += nt) stage[i] = res[i0 + i];

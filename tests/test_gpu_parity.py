@@ -651,6 +651,8 @@ def test_dsp_unsupported_and_empty():
     dict(downsample=10, squelch_level=300, post_downsample=1, deemph_a=5, dc_block=False), # squelch around the level
     dict(downsample=4, squelch_level=150, post_downsample=2, deemph_a=2, dc_block=True),
     dict(downsample=1, squelch_level=40, post_downsample=5, deemph_a=7, dc_block=True),
+    dict(downsample=3, squelch_level=0, post_downsample=2, deemph_a=4, dc_block=False),    # a power of two: exact quotients
+    dict(downsample=5, squelch_level=0, post_downsample=1, deemph_a=64, dc_block=True),
 ])
 def test_rtlfm_full_demod_vs_oracle(cfg):
     """sdrx_rtlfm_full_dev against the literal restatement of rtl_fm's full_demod (parity unpinned: rtl_fm.c needs

@@ -521,3 +521,18 @@ def test_rtlfm_full_demod_restatement_properties():
     mean = int(int(plain.astype(np.int64).sum()) / m)
     a = int((mean + 0) / 10)
     assert post_b[1] == a and np.array_equal(p_b[:m], (plain.astype(np.int32) - a).astype(np.int16))
+
+
+def test_deemph_magic_division_is_exact_on_its_whole_domain():
+    """The de-emphasis kernel (rtlfm_post_kernel) replaces rtl_fm's `(d +- a/2) / a` (C division, truncating) by a
+    signed multiply-high with magic = floor(2^32 / a) + 1: trunc(x / a) = (x * magic) >> 32 for x >= 0 and that + 1 for
+    x < 0.  Checked here for every divisor the kernel takes that path for (3 <= a < 2048) and every x it can meet
+    there (avg and the sample both in the int16 range: |d| <= 65535, |x| <= 65535 + 1023)."""
+    x = np.arange(-(65535 + 1023), 65535 + 1024, dtype=np.int64)
+    neg = (x < 0).astype(np.int64)
+    for a in range(3, 2048):
+        magic = 0x100000000 // a + 1
+        assert magic < 1 << 31
+        got = ((x * magic) >> 32) + neg
+        want = np.sign(x) * (np.abs(x) // a)  # truncation towards zero
+        assert np.array_equal(got, want), a
