@@ -654,7 +654,7 @@ def test_dsp_unsupported_and_empty():
     dict(downsample=3, squelch_level=0, post_downsample=2, deemph_a=4, dc_block=False),    # a power of two: exact quotients
     dict(downsample=5, squelch_level=0, post_downsample=1, deemph_a=64, dc_block=True),
 ])
-def test_rtlfm_full_demod_vs_oracle(cfg):
+def test_rtlfm_full_demod_vs_oracle(cfg, expect_both=True):
     """sdrx_rtlfm_full_dev against the literal restatement of rtl_fm's full_demod (parity unpinned: rtl_fm.c needs
     librtlsdr): 9 channels with amplitudes on both sides of the squelch level (some channels squelched in some calls
     only, so squelch_hits counts up and resets), four calls of ragged lengths with every state carried: pcm rows
@@ -686,7 +686,7 @@ def test_rtlfm_full_demod_vs_oracle(cfg):
         assert np.array_equal(pcm.cpu().numpy(), pcm_ref), call
         assert np.array_equal(fm.state[fm.cur].cpu().numpy(), sts), call
         assert np.array_equal(fm.post_state.cpu().numpy(), posts), call
-    if cfg["squelch_level"]:
+    if cfg["squelch_level"] and expect_both:
         assert posts[:, 2].max() > 0 and posts[:, 2].min() == 0  # both squelched and open channels were seen
 
 
