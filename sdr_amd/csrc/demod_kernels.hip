@@ -564,45 +564,11 @@ __device__ __forceinline__ void rtlfm_lowpassed(const uint8_t *__restrict__ x, l
     j = (int)(int16_t)sj;
 }
 
-// Power squelch, first half (rtl_fm.c:650-660): t = sum, p = sum of squares of the call's lowpassed[] values,
-// exact in 64-bit integers in any order.  acc[2 chan] += t, acc[2 chan + 1] += p (zeroed by the launcher).
-__global__ void __launch_bounds__(256) rtlfm_power_kernel(const uint8_t *__restrict__ iq, size_t n, size_t nchan,
-                                                          size_t in_pitch, int ds, int rotate90,
-                                                          const int32_t *__restrict__ st_in,
-                                                          unsigned long long *__restrict__ acc)
-{
-    const size_t chan = (size_t)blockIdx.z * 65535u + blockIdx.y;
-    if (chan >= nchan) return;
-    const uint8_t *x = iq + 2 * chan * in_pitch;
-    const int32_t *si = st_in + 5 * chan;
-    const RtlfmCarry c = {si[0], si[1], si[2]};
-    const long long m_total = ((long long)c.prev_index + (long long)n) / ds;
-    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    long long t = 0, p = 0;
-    if (m < m_total) {
-        int r, j;
-        rtlfm_lowpassed(x, m, ds, rotate90, c, r, j);
-        t = (long long)r + j;
-        p = (long long)r * r + (long long)j * j;
-    }
-    __shared__ long long red_t[4], red_p[4];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        t += __shfl_xor(t, off);
-        p += __shfl_xor(p, off);
-    }
-    if ((threadIdx.x & 63) == 0) red_t[threadIdx.x >> 6] = t, red_p[threadIdx.x >> 6] = p;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        t = red_t[0] + red_t[1] + red_t[2] + red_t[3];
-        p = red_p[0] + red_p[1] + red_p[2] + red_p[3];
-        if (t | p) {
-            atomicAdd(acc + 2 * chan, (unsigned long long)t);
-            atomicAdd(acc + 2 * chan + 1, (unsigned long long)p);
-        }
-    }
-}
-
+// Power squelch (rtl_fm.c:650-667, full_demod :752-761).  First half: t = sum, p = sum of squares of the call's
+// lowpassed[] values, exact in 64-bit integers in any order: rtlfm_kernel adds its workgroups' shares to acc[2 chan],
+// acc[2 chan + 1] (zeroed by the launcher) while it demodulates as if the channel were open; rtlfm_post_kernel, which
+// runs when every share is in, takes the decision and gives a squelched channel what fm_demod makes of a zeroed
+// lowpassed[]: a row of zeros (atan2(0, 0)) and pre_r = pre_j = 0.
 // second half (rtl_fm.c:661-667 and full_demod :752-761): sr = (int)sqrt((p - err) / len) < squelch_level, evaluated
 // as !(v >= sq_thr) with sq_thr the smallest double whose rounded square root reaches the level (NaN / negative v
 // convert to INT_MIN on the CPU: squelched)
@@ -620,10 +586,10 @@ __global__ void __launch_bounds__(256) rtlfm_kernel(const uint8_t *__restrict__ 
                                                     size_t in_pitch, int ds,
                                                     int rotate90, const int32_t *__restrict__ st_in,
                                                     int32_t *__restrict__ st_out, int16_t *__restrict__ pcm,
-                                                    size_t out_pitch, const unsigned long long *__restrict__ acc,
-                                                    double sq_thr, int32_t *__restrict__ post_state)
+                                                    size_t out_pitch, unsigned long long *__restrict__ acc)
 {
     __shared__ int xr[256], xj[256];
+    __shared__ long long red_t[4], red_p[4];
     const size_t chan = (size_t)blockIdx.z * 65535u + blockIdx.y; // grid.y is limited to 65535
     if (chan >= nchan) return;                                     // a whole workgroup
     const uint8_t *x = iq + 2 * chan * in_pitch;
@@ -631,17 +597,32 @@ __global__ void __launch_bounds__(256) rtlfm_kernel(const uint8_t *__restrict__ 
     const RtlfmCarry c = {si[0], si[1], si[2]};
     const long long m_total = ((long long)c.prev_index + (long long)n) / ds; // outputs of this call
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool mute = acc != nullptr && rtlfm_squelched(acc, chan, m_total, sq_thr); // lowpassed[] zeroed (:755-757)
     int ar = 0, aj = 0;
-    if (m < m_total && !mute) rtlfm_lowpassed(x, m, ds, rotate90, c, ar, aj);
+    if (m < m_total) rtlfm_lowpassed(x, m, ds, rotate90, c, ar, aj);
     xr[threadIdx.x] = ar;
     xj[threadIdx.x] = aj;
+    if (acc != nullptr) { // (uniform) this workgroup's share of the channel's power sums
+        long long t = (long long)ar + aj, p = (long long)ar * ar + (long long)aj * aj;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            t += __shfl_xor(t, off);
+            p += __shfl_xor(p, off);
+        }
+        if ((threadIdx.x & 63) == 0) red_t[threadIdx.x >> 6] = t, red_p[threadIdx.x >> 6] = p;
+    }
     __syncthreads();
+    if (acc != nullptr && threadIdx.x == 0) {
+        const long long t = red_t[0] + red_t[1] + red_t[2] + red_t[3], p = red_p[0] + red_p[1] + red_p[2] + red_p[3];
+        if (t | p) {
+            atomicAdd(acc + 2 * chan, (unsigned long long)t);
+            atomicAdd(acc + 2 * chan + 1, (unsigned long long)p);
+        }
+    }
     if (m < m_total) {
         int br = 0, bj = 0;
         if (threadIdx.x > 0) { br = xr[threadIdx.x - 1]; bj = xj[threadIdx.x - 1]; }
         else if (m == 0) { br = si[3]; bj = si[4]; }              // pre_r, pre_j (rtl_fm.c:523)
-        else if (!mute) rtlfm_lowpassed(x, m - 1, ds, rotate90, c, br, bj); // first thread of a later workgroup
+        else rtlfm_lowpassed(x, m - 1, ds, rotate90, c, br, bj); // first thread of a later workgroup
         bj = -bj;                                                  // multiply(a, conj b): rtl_fm.c:422-426,432
         const int cr = ar * br - aj * bj, cj = aj * br + ar * bj;
         const double angle = sdrx_atan2((double)cj, (double)cr);
@@ -656,7 +637,6 @@ __global__ void __launch_bounds__(256) rtlfm_kernel(const uint8_t *__restrict__ 
         st_out[5 * chan + 1] = sj;
         st_out[5 * chan + 2] = (int32_t)(((long long)c.prev_index + (long long)n) % ds);
         if (m_total == 0) { st_out[5 * chan + 3] = si[3]; st_out[5 * chan + 4] = si[4]; }
-        if (acc != nullptr) post_state[4 * chan + 2] = mute ? post_state[4 * chan + 2] + 1 : 0; // squelch_hits (:754,:759)
     }
 }
 
@@ -670,7 +650,9 @@ constexpr int DEEMPH_CHUNK = 4096;
 
 __global__ void __launch_bounds__(256) rtlfm_post_kernel(int16_t *__restrict__ pcm_all, size_t out_pitch, size_t n, int ds,
                                                          int step, int deemph_a, int dc_block,
-                                                         const int32_t *__restrict__ st_in, int32_t *__restrict__ post_state)
+                                                         const int32_t *__restrict__ st_in, int32_t *__restrict__ post_state,
+                                                         const unsigned long long *__restrict__ acc, double sq_thr,
+                                                         int32_t *__restrict__ st_out)
 {
     __shared__ long long red[4];
     __shared__ __align__(16) int16_t stage[DEEMPH_CHUNK];
@@ -679,6 +661,15 @@ __global__ void __launch_bounds__(256) rtlfm_post_kernel(int16_t *__restrict__ p
     int16_t *res = pcm_all + chan * out_pitch;
     int32_t *ps = post_state + 4 * chan;
     int len = (int)(((long long)st_in[5 * chan + 2] + (long long)n) / ds); // result_len after fm_demod
+    if (acc != nullptr) { // the squelch decision (every thread the same), now that the channel's sums are complete
+        const bool mute = rtlfm_squelched(acc, chan, len, sq_thr);
+        if (mute) { // lowpassed[] zeroed before fm_demod (:755-757)
+            for (int i = (int)tid; i < len; i += nt) res[i] = 0;
+            if (tid == 0 && len > 0) st_out[5 * chan + 3] = 0, st_out[5 * chan + 4] = 0; // rtl_fm.c:543-544
+        }
+        if (tid == 0) ps[2] = mute ? ps[2] + 1 : 0; // squelch_hits (:754,:759)
+        __syncthreads();
+    }
     if (step > 1) {
         const int W = (len + step - 1) / step;
         for (int k0 = 0; k0 < W; k0 += nt) { // output k lands below every value a later window reads
@@ -864,7 +855,7 @@ int launch_rtlfm(const uint8_t *iq, size_t n, size_t nchan, size_t in_pitch, int
     int rc = rtlfm_grid(n, nchan, ds, grid);
     if (rc != SDRX_OK) return rc;
     hipLaunchKernelGGL(rtlfm_kernel, grid, dim3(256), 0, s, iq, n, nchan, in_pitch, ds, rotate90, st_in, st_out, pcm,
-                       out_pitch, (const unsigned long long *)nullptr, 0.0, (int32_t *)nullptr);
+                       out_pitch, (unsigned long long *)nullptr);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }
@@ -900,19 +891,17 @@ int launch_rtlfm_full(const sdrx_rtlfm_params *p, const uint8_t *iq, size_t n, s
     dim3 grid;
     int rc = rtlfm_grid(n, nchan, ds, grid);
     if (rc != SDRX_OK) return rc;
-    const unsigned long long *acc = nullptr;
+    unsigned long long *acc = nullptr;
     double thr = 0.0;
     if (p->squelch_level) {
         SDRX_HIP(hipMemsetAsync(work, 0, nchan * 2 * sizeof(int64_t), s));
-        hipLaunchKernelGGL(rtlfm_power_kernel, grid, dim3(256), 0, s, iq, n, nchan, in_pitch, ds, p->rotate90, st_in,
-                           (unsigned long long *)work);
-        acc = (const unsigned long long *)work;
+        acc = (unsigned long long *)work;
         thr = squelch_threshold(p->squelch_level);
     }
     hipLaunchKernelGGL(rtlfm_kernel, grid, dim3(256), 0, s, iq, n, nchan, in_pitch, ds, p->rotate90, st_in, st_out, pcm,
-                       out_pitch, acc, thr, post_state);
+                       out_pitch, acc);
     hipLaunchKernelGGL(rtlfm_post_kernel, dim3((unsigned)nchan), dim3(256), 0, s, pcm, out_pitch, n, ds, step, p->deemph_a,
-                       p->dc_block, st_in, post_state);
+                       p->dc_block, st_in, post_state, (const unsigned long long *)acc, thr, st_out);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }
