@@ -89,7 +89,8 @@ pay = torch.zeros(1024, 256, 250, dtype=torch.uint8, device=dev)
 summ = torch.zeros(1024, 4, dtype=torch.int64, device=dev)
 L = _lib.lib()
 import ctypes as C  # noqa: E402
-for name, bits in (("deframe dense packets", dense), ("deframe noise", noise)):
+b2b = torch.tensor(np.stack([framed_bit_stream(nb, 10 + c, packet_every=1, p_false_uw=0.0) for c in range(64)]), device=dev).repeat(16, 1).contiguous()
+for name, bits in (("deframe packets + a bare unique word every ~500 bits", dense), ("deframe back-to-back packets", b2b), ("deframe noise", noise)):
     def run():
         _lib.check(L.sdrx_deframe_dev(C.c_void_p(bits.data_ptr()), nb, 1024, nb, 1, C.c_void_p(ev.data_ptr()),
                                       C.c_void_p(pay.data_ptr()), 256, C.c_void_p(summ.data_ptr()), None))
@@ -99,7 +100,7 @@ for name, bits in (("deframe dense packets", dense), ("deframe noise", noise)):
     rows.append({"kernel": name + " (1024 ch x 2^18 bits)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
                  "algorithmic_GBps": 1.0 * tot / t / 1e9, "frac_of_8TBps": 1.0 * tot / t / 1e9 / PEAK,
                  "events_per_channel": float(summ[:, 0].double().mean().item())})
-del dense, noise, ev, pay, summ
+del dense, b2b, noise, ev, pay, summ
 # DSP primitives: 16384 rows x 2^13 doubles (1 GiB), read + write = 16 B per sample
 nchan, n = 16384, 1 << 13
 x = torch.randn(nchan, n, dtype=torch.float64, device=dev) * 50

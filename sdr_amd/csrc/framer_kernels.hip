@@ -19,7 +19,10 @@ namespace sdrx {
 constexpr int PKT_BITS = 2032;          // MAX_PKT_SIZE_BITS = (250 + 4) * 8, PacketFramer.h:40-54
 constexpr unsigned UW_ONES = 0x735Fu;   // PACKET_FRAMER_UNIQUE_WORD (PacketFramer.h:17-19), bit i = word[i]
 constexpr int SEARCH_SPAN = 2048;       // positions examined per workgroup step (8 per lane)
-constexpr int WIN_BYTES = 4352;          // 272 x 16: the positions searched, a packet more, and up to 15 bytes of alignment
+constexpr int WIN_NEED = SEARCH_SPAN - 1 + PKT_BITS; // a search step at window offset w reads below w + WIN_NEED: the
+                                                      // positions searched and a whole packet behind the last of them
+constexpr int WIN_BYTES = 4 * 4352;      // the window kept in LDS: a step needs WIN_NEED + up to 15 bytes of alignment; four
+                                         // times that, so that a stretch of packets (or of noise) is loaded once
 
 __device__ __forceinline__ unsigned to_byte(const uint8_t *b) // PacketFramer.h:537-549: MSB first, == 1
 {
@@ -74,23 +77,39 @@ __global__ void __launch_bounds__(256) deframe_kernel(const uint8_t *__restrict_
     unsigned long long nev = 0, zero_returns = 0;
     const long long N = (long long)n, lim = N - PKT_BITS; // fronts below lim: a whole packet and more is left
 
+    long long wbase = -1; // win[0 .. wlen) = bits[wbase .. wbase + wlen) (2 beyond the stream's end)
+    int wlen = 0;
     while (N - p > PKT_BITS) { // the receiver's loop condition, at the start of a deserialize call
         // ---- first front q in [p, lim) whose 16 bits are the unique word
-        long long q = -1, wbase = -1;
+        long long q = -1;
         for (long long base = p; base < lim && q < 0; base += SEARCH_SPAN) {
-            // the window starts at the 16-byte boundary at or below `base`: one 16-byte load per lane
-            long long start = base - (long long)((size_t)(bits + base) & 15);
-            if (start < 0) start = base; // (the channel's first bytes: no reading in front of the buffer)
-            const bool vec = (((size_t)(bits + start)) & 15) == 0;
-            for (int e = (int)tid * 16; e < WIN_BYTES; e += 256 * 16) {
-                if (vec && start + e + 16 <= N) {
-                    *(uint4 *)(win + e) = *(const uint4 *)(bits + start + e);
-                } else {
-                    for (int k = 0; k < 16; k++) win[e + k] = (start + e + k < N) ? bits[start + e + k] : (uint8_t)2;
+            bool refilled = false;
+            if (wbase < 0 || base < wbase || base - wbase + WIN_NEED > wlen) { // (uniform) this step leaves the window
+                // the window starts at the 16-byte boundary at or below `base`: 16-byte loads
+                long long start = base - (long long)((size_t)(bits + base) & 15);
+                if (start < 0) start = base; // (the channel's first bytes: no reading in front of the buffer)
+                const bool vec = (((size_t)(bits + start)) & 15) == 0;
+                for (int e = (int)tid * 16; e < WIN_BYTES; e += 256 * 16) {
+                    if (vec && start + e + 16 <= N) {
+                        *(uint4 *)(win + e) = *(const uint4 *)(bits + start + e);
+                    } else {
+                        for (int k = 0; k < 16; k++) win[e + k] = (start + e + k < N) ? bits[start + e + k] : (uint8_t)2;
+                    }
+                }
+                wbase = start;
+                wlen = WIN_BYTES;
+                refilled = true;
+            }
+            const int woff = (int)(base - wbase);
+            if (refilled) __syncthreads();
+            if (base == p) { // the front itself -- a packet right behind the last one: every wave looks for itself (the
+                const unsigned lane = tid & 63; // window is the same for all), no barrier, no search
+                const bool ok = lane >= 16 || win[woff + lane] == ((UW_ONES >> lane) & 1u);
+                if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) {
+                    q = base;
+                    break;
                 }
             }
-            wbase = start;
-            const int woff = (int)(base - start);
             if (tid == 0) s_min = 0x7fffffff;
             __syncthreads();
             unsigned ones = 0, zeros = 0;
@@ -166,9 +185,10 @@ __global__ void __launch_bounds__(256) deframe_kernel(const uint8_t *__restrict_
         }
 
         // ---- header at q, at least PKT_BITS bits from there: length, crc, data (PacketFramer.h:474-512)
-        if (wbase < 0 || q < wbase || q + PKT_BITS > wbase + WIN_BYTES) { // (only after the literal replay)
+        if (wbase < 0 || q < wbase || q + PKT_BITS > wbase + wlen) { // (only after the literal replay)
             for (int e = (int)tid; e < PKT_BITS; e += 256) win[e] = bits[q + e];
             wbase = q;
+            wlen = PKT_BITS;
             __syncthreads();
         }
         const uint8_t *hdr = win + (q - wbase);
