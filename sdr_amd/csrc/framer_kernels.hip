@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) deframe_kernel(const uint8_t *__restrict_
     __shared__ unsigned crc_part[4];
     __shared__ uint8_t pkt[256];
     __shared__ __align__(16) uint8_t win[WIN_BYTES]; // the stream from (just before) the search base on
-    __shared__ int s_min;
+    __shared__ int s_min, s_near;
     __shared__ int s_ok;
     __shared__ long long s_tail_front, s_tail_q;
     __shared__ unsigned long long s_tail_zero;
@@ -107,6 +107,33 @@ __global__ void __launch_bounds__(256) deframe_kernel(const uint8_t *__restrict_
                 const bool ok = lane >= 16 || win[woff + lane] == ((UW_ONES >> lane) & 1u);
                 if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) {
                     q = base;
+                    break;
+                }
+                // the next 512 positions by the first wave alone (8 per lane; the lowest lane with a hit holds the lowest
+                // position): one barrier, and the other waves issue nothing -- the kernel is bound by the instructions
+                // a workgroup issues per event, and in a busy stream the next header is seldom far
+                if (tid < 64) {
+                    unsigned ones = 0, zeros = 0;
+#pragma unroll
+                    for (int k = 0; k < 23; k++) {
+                        const unsigned v = win[woff + 8 * tid + k];
+                        ones |= (v == 1 ? 1u : 0u) << k;
+                        zeros |= (v == 0 ? 1u : 0u) << k;
+                    }
+                    int first = 0x7fffffff;
+#pragma unroll
+                    for (int o = 7; o >= 0; o--) {
+                        const bool hit = ((ones >> o) & 0xffffu) == UW_ONES && ((zeros >> o) & 0xffffu) == (~UW_ONES & 0xffffu);
+                        if (hit && base + 8 * (long long)tid + o < lim) first = 8 * (int)tid + o;
+                    }
+                    const unsigned long long any = __builtin_amdgcn_ballot_w64(first != 0x7fffffff);
+                    const int best = any ? __builtin_amdgcn_readlane(first, (int)__builtin_ctzll(any)) : 0x7fffffff;
+                    if (tid == 0) s_near = best;
+                }
+                __syncthreads();
+                const int near = s_near; // (written again only after the barriers that end this event)
+                if (near != 0x7fffffff) {
+                    q = base + near;
                     break;
                 }
             }
@@ -192,7 +219,9 @@ __global__ void __launch_bounds__(256) deframe_kernel(const uint8_t *__restrict_
             __syncthreads();
         }
         const uint8_t *hdr = win + (q - wbase);
-        const unsigned len = to_byte(hdr + 16);
+        // length and crc bytes (to_byte: MSB first) out of one ballot per wave over the header's first 64 bits
+        const unsigned long long hbits = __builtin_amdgcn_ballot_w64(hdr[tid & 63] == 1);
+        const unsigned len = __brev((unsigned)(hbits >> 16) & 0xffu) >> 24;
         unsigned crc = 0;
         int kind;
         if (len > 250) {
@@ -200,7 +229,7 @@ __global__ void __launch_bounds__(256) deframe_kernel(const uint8_t *__restrict_
             p = q + 1;
             __syncthreads(); // every wave has read the header before the next search refills the window
         } else {
-            crc = to_byte(hdr + 24);
+            crc = __brev((unsigned)(hbits >> 24) & 0xffu) >> 24;
             if (tid < 250) pkt[tid] = (uint8_t)to_byte(hdr + 32 + 8 * tid);
             __syncthreads();
             unsigned term = 0;
