@@ -66,12 +66,18 @@ template <int KIND> __device__ __forceinline__ double iir_step(double x, double 
     return y;
 }
 
-// One channel per lane: the recurrences are serial in time.  A wave owns 64 rows and walks them in
-// chunks of 16 samples (one 128-byte line per row).  Global accesses are row-coalesced -- an
-// instruction covers 4 rows x 16 consecutive samples -- and a wave-private LDS tile (pitch 17: the
+// One channel per lane: the recurrences are serial in time.  A wave owns CW rows and walks them in
+// chunks of IC samples (four 128-byte lines per row).  Global accesses are row-coalesced -- an
+// instruction covers 64 / IC rows x IC consecutive samples -- and a wave-private LDS tile (pitch IC + 1: the
 // per-lane reads are conflict-free) turns them into each lane's own run; the next chunk's loads are
 // in flight while the current one is computed.  No s_barrier: nothing is shared between waves.
-constexpr int IC = 16, IPITCH = IC + 1;
+// IC = samples per chunk.  Measured, DC blocker, 16 rows per wave (ms): 16384 rows x 8192: 16 0.53, 32 0.46, 64 0.47;
+// 131072 x 1024: 0.52 / 0.49 / 0.46; 65536 x 2048: 0.56 / 0.53 / 0.45; 1024 x 131072 (4 rows per wave): 4.55 / 3.72 / 3.49.
+// (64 rows per wave with 64-sample chunks spills: 2-5 ms; the launcher never picks it.)
+#ifndef SDRX_IIR_IC
+#define SDRX_IIR_IC 64
+#endif
+constexpr int IC = SDRX_IIR_IC, IPITCH = IC + 1, RPI = 64 / IC; // RPI: rows covered by one load instruction
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -98,7 +104,7 @@ template <int KIND, int CW>
 __global__ __launch_bounds__(64) void iir_kernel(const double *x, double *y, size_t n, size_t nchan, size_t pitch, IirCoef k,
                                                  double *state)
 {
-    constexpr int NI = CW / 4; // load instructions per chunk: each covers 4 rows x 16 samples
+    constexpr int NI = (CW + RPI - 1) / RPI; // load instructions per chunk: each covers RPI rows x IC samples
     __shared__ double tile[CW * IPITCH];
     const unsigned l = threadIdx.x, sub = l / IC, col = l % IC, cl = l % CW;
     const size_t c0 = (size_t)blockIdx.x * CW, c = c0 + cl;
@@ -112,12 +118,13 @@ __global__ __launch_bounds__(64) void iir_kernel(const double *x, double *y, siz
     auto load = [&](size_t s0) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
-            nxt[i] = (c0 + 4 * i + sub < nchan && s0 + col < n) ? DSP_LOAD(x + row0 + (size_t)(4 * i) * pitch + s0) : 0.0;
+            nxt[i] = (RPI * i + sub < CW && c0 + RPI * i + sub < nchan && s0 + col < n) ? DSP_LOAD(x + row0 + (size_t)(RPI * i) * pitch + s0) : 0.0;
     };
     load(0);
     for (size_t s0 = 0; s0 < n; s0 += IC) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) tile[(4 * i + sub) * IPITCH + col] = nxt[i];
+        for (int i = 0; i < NI; i++)
+            if (RPI * i + sub < CW) tile[(RPI * i + sub) * IPITCH + col] = nxt[i];
         wave_lds_sync();
         if (s0 + IC < n) load(s0 + IC);
         double v[IC];
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(64) void iir_kernel(const double *x, double *y, siz
         wave_lds_sync();
 #pragma unroll
         for (int i = 0; i < NI; i++)
-            if (c0 + 4 * i + sub < nchan && s0 + col < n) DSP_STORE(tile[(4 * i + sub) * IPITCH + col], y + row0 + (size_t)(4 * i) * pitch + s0);
+            if (RPI * i + sub < CW && c0 + RPI * i + sub < nchan && s0 + col < n) DSP_STORE(tile[(RPI * i + sub) * IPITCH + col], y + row0 + (size_t)(RPI * i) * pitch + s0);
         wave_lds_sync();
     }
     if (carried && l < CW)
@@ -451,8 +458,8 @@ extern "C" int sdrx_iir_dev(int kind, const double *coef, const double *x, doubl
     IirCoef k = {{0, 0, 0, 0, 0}};
     for (int j = 0; j < ncoef[kind]; j++) k.c[j] = coef[j];
     if (kind == K_DC && (const double *)y == x) k.c[1] = 1.0; // aliased call: the reference's own in-place behaviour
-    // rows per wave: the largest of 64 / 16 / 4 that still gives every SIMD of the part (1024) a wave
-    int cw = nchan >= 64 * 1024 ? 64 : (nchan >= 16 * 1024 ? 16 : 4);
+    // rows per wave: 16 once that gives every SIMD of the part (1024) a wave, else 4 (64 only on request)
+    int cw = nchan >= 16 * 1024 ? 16 : 4;
     if (const int v = tuning().iir_cw; v == 64 || v == 16 || v == 4) cw = v;
     hipStream_t s = (hipStream_t)stream;
     switch (kind) {
