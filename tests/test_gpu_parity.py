@@ -514,6 +514,34 @@ def test_ones_zeros_confidence_walk_in_segments(nchan, n):
         assert cnt2.cpu().tolist() == want2
 
 
+def test_ones_zeros_confidence_walk_under_stream_capture():
+    """A long stream while its stream is being captured into a HIP graph: the segmented form orders its calls with an
+    event, which a capture must not see, so the one-workgroup form is captured instead; the replayed graph walks the
+    counter like the literal loop, twice in a row (the second replay starts from the first one's counter)."""
+    rng = np.random.default_rng(99)
+    n = 700001
+    mag = np.where(rng.random((1, n)) < 0.52, 100.0, 10.0)
+    re, im = mag, np.zeros((1, n))
+    re_d, im_d = _rows_dev(re), _rows_dev(im)
+    cnt = torch.tensor([40], dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        device.ones_zeros_confidence(re_d, im_d, 300, cnt)
+    cnt.fill_(40)
+    g.replay()
+    torch.cuda.synchronize()
+    first = L.orc_ones_zeros_confidence(np.ascontiguousarray(re[0]), np.ascontiguousarray(im[0]), n, 300, 40)
+    assert int(cnt.item()) == first
+    g.replay()
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == L.orc_ones_zeros_confidence(np.ascontiguousarray(re[0]), np.ascontiguousarray(im[0]), n, 300, first)
+    # and outside a capture the same call takes the segmented form and agrees
+    cnt2 = torch.tensor([40], dtype=torch.int32, device="cuda")
+    device.ones_zeros_confidence(re_d, im_d, 300, cnt2)
+    assert int(cnt2.item()) == first
+
+
 # =============================================================================== DSP primitives (SURVEY 8f rank 3)
 
 @pytest.mark.parametrize("cw", [4, 16, 64])
