@@ -363,20 +363,43 @@ template <int R> __device__ __forceinline__ void fft_group(v2d *x, const v2d *tw
     __syncthreads();
 }
 
+// Persistent workgroups: each walks the transforms blockIdx.x, blockIdx.x + gridDim.x, ...; the twiddles are staged
+// once, and the NEXT transform's samples are loaded into registers (PER = ceil(N / 256) <= 16 per thread) before the
+// current one's stages run, so that the load latency is not a phase of its own.
+constexpr unsigned FFT_PER_MAX = SDRX_FFT_MAX / 256;
+
 __global__ __launch_bounds__(256) void fft_kernel(double *iq, const v2d *__restrict__ tw_g, unsigned N, unsigned log2n,
-                                                  size_t pitch)
+                                                  size_t pitch, unsigned nchan)
 {
     extern __shared__ v2d fft_lds[];
     v2d *tw = fft_lds, *x = fft_lds + N / 2;
-    v2d *g = reinterpret_cast<v2d *>(iq) + (size_t)blockIdx.x * pitch;
-    for (unsigned i = threadIdx.x; i < N; i += 256) x[fft_pad(__brev(i) >> (32 - log2n))] = g[i];
     for (unsigned j = threadIdx.x; j < N / 2; j += 256) tw[j] = tw_g[j];
-    __syncthreads();
-    unsigned st = 0;
-    for (; st + 3 <= log2n; st += 3) fft_group<3>(x, tw, st, log2n, N);
-    if (log2n - st == 2) fft_group<2>(x, tw, st, log2n, N);
-    if (log2n - st == 1) fft_group<1>(x, tw, st, log2n, N);
-    for (unsigned i = threadIdx.x; i < N; i += 256) g[i] = x[fft_pad(i)];
+    v2d nxt[FFT_PER_MAX];
+    auto fetch = [&](unsigned row) {
+        const v2d *g = reinterpret_cast<const v2d *>(iq) + (size_t)row * pitch;
+#pragma unroll
+        for (unsigned q = 0; q < FFT_PER_MAX; q++) {
+            const unsigned i = threadIdx.x + 256 * q;
+            if (i < N) nxt[q] = g[i];
+        }
+    };
+    if (blockIdx.x < nchan) fetch(blockIdx.x);
+    for (unsigned row = blockIdx.x; row < nchan; row += gridDim.x) {
+        __syncthreads(); // the previous transform's last reads of x are done (and, the first time, tw is complete)
+#pragma unroll
+        for (unsigned q = 0; q < FFT_PER_MAX; q++) {
+            const unsigned i = threadIdx.x + 256 * q;
+            if (i < N) x[fft_pad(__brev(i) >> (32 - log2n))] = nxt[q];
+        }
+        if (row + gridDim.x < nchan) fetch(row + gridDim.x);
+        __syncthreads();
+        unsigned st = 0;
+        for (; st + 3 <= log2n; st += 3) fft_group<3>(x, tw, st, log2n, N);
+        if (log2n - st == 2) fft_group<2>(x, tw, st, log2n, N);
+        if (log2n - st == 1) fft_group<1>(x, tw, st, log2n, N);
+        v2d *g = reinterpret_cast<v2d *>(iq) + (size_t)row * pitch;
+        for (unsigned i = threadIdx.x; i < N; i += 256) g[i] = x[fft_pad(i)];
+    }
 }
 
 constexpr int FFT_MAX_LOG2 = 12;
@@ -568,7 +591,11 @@ extern "C" int sdrx_fft_dev(double *iq, size_t n, size_t nchan, size_t pitch, vo
     int rc = fft_twiddles(log2n, (hipStream_t)stream, &tw);
     if (rc != SDRX_OK) return rc;
     size_t lds = (n / 2 + n + n / 8 + 1) * sizeof(v2d);
-    fft_kernel<<<(unsigned)nchan, 256, lds, (hipStream_t)stream>>>(iq, tw, (unsigned)n, log2n, pitch);
+    // as many workgroups as are resident at once (LDS or the 8-workgroups-of-256 limit per CU), each looping over rows
+    size_t per_cu = (160 * 1024) / (lds + 256);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    const size_t grid = nchan < per_cu * 256 ? nchan : per_cu * 256;
+    fft_kernel<<<(unsigned)grid, 256, lds, (hipStream_t)stream>>>(iq, tw, (unsigned)n, log2n, pitch, (unsigned)nchan);
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }
