@@ -127,7 +127,14 @@ for name, fn, bytes_per in (("iir dc_block", lambda: device.iir(device.IIR_DC_BL
     tot = nchan * n
     rows.append({"kernel": name + " (16384 rows x 2^13)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
                  "algorithmic_GBps": bytes_per * tot / t / 1e9, "frac_of_8TBps": bytes_per * tot / t / 1e9 / PEAK})
-del x, z
+del x
+for nfft in (64, 256, 1024, 4096):  # the other lengths, same 2^26 points
+    z = z.view(-1, nfft)
+    t = timed(lambda: device.fft(z), iters=10, warm=2)
+    tot = nchan * n
+    rows.append({"kernel": f"fft {nfft} points x {z.shape[0]}", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
+                 "algorithmic_GBps": 16.0 * tot / t / 1e9, "frac_of_8TBps": 16.0 * tot / t / 1e9 / PEAK})
+del z
 # round 2: the modulators as device kernels (output-bound: 8 B written per output sample), the PSK stages of cfg3
 nchan, nbit, spb = 1024, 1 << 14, 16
 bits = torch.randint(0, 2, (nchan, nbit), device=dev, dtype=torch.uint8)

@@ -65,6 +65,8 @@ Tuning &tuning()
         x.psk_pieces = env_int("SDRX_PSK_PIECES", d.psk_pieces);
         x.fsk_rows = env_int("SDRX_FSK_ROWS", d.fsk_rows);
         x.iir_cw = env_int("SDRX_IIR_CW", d.iir_cw);
+        x.fft_nt = env_int("SDRX_FFT_NT", d.fft_nt);
+        x.fft_tile = env_int("SDRX_FFT_TILE", d.fft_tile);
         return x;
     }();
     return t;
@@ -166,6 +168,8 @@ extern "C" int sdrx_tune(const char *name, const char *value)
     else if (strcmp(name, "SDRX_PSK_PIECES") == 0) t.psk_pieces = dflt ? d.psk_pieces : v;
     else if (strcmp(name, "SDRX_FSK_ROWS") == 0) t.fsk_rows = dflt ? d.fsk_rows : v;
     else if (strcmp(name, "SDRX_IIR_CW") == 0) t.iir_cw = dflt ? d.iir_cw : v;
+    else if (strcmp(name, "SDRX_FFT_NT") == 0) t.fft_nt = dflt ? d.fft_nt : v;
+    else if (strcmp(name, "SDRX_FFT_TILE") == 0) t.fft_tile = dflt ? d.fft_tile : v;
     else {
         set_error("sdrx_tune: unknown switch %s", name);
         return SDRX_EINVAL;

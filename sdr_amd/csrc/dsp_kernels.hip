@@ -333,72 +333,95 @@ __global__ void fft_twiddle_kernel(v2d *tw, unsigned N)
     tw[j] = v2d{cs, sn}; // std::polar(1.0, theta)
 }
 
-__device__ __forceinline__ unsigned fft_pad(unsigned i) { return i + (i >> 3); } // one spare slot per 8: odd LDS strides
+// LDS layouts (slot = 16 bytes).  A 16-byte read is served in four groups of 16 lanes on banks = slot mod 16, a 16-byte
+// write in eight groups of 8 lanes on slot mod 8 (MI355X LDS).  Data: the index with its higher octal digits folded into
+// the lowest by xor -- a bijection that needs no spare slots and leaves the bit-reversed scatter, every stage group's
+// strided reads and writes, and the final row read (nearly) conflict-free.  Twiddles: the same with hexadecimal digits,
+// so that the multiples of 2^m a stage reads spread over all 16 banks (they sat on one: 21 LDS cycles per read instead of
+// 4; build/fft_lds_sim.py models every access).  Both folds are linear over xor: fold(a + b) = fold(a) ^ fold(b) where a
+// and b share no bits, which lets the wave-uniform part of an index be folded on the scalar unit.
+__device__ __forceinline__ unsigned fft_pad(unsigned i) { return i ^ ((i >> 3) & 7) ^ ((i >> 6) & 7) ^ ((i >> 9) & 7); }
+__device__ __forceinline__ unsigned fft_twz(unsigned j) { return j ^ ((j >> 4) & 15) ^ ((j >> 8) & 15); }
+static_assert(SDRX_FFT_MAX <= 4096, "fft_pad folds four octal digits, fft_twz three hexadecimal ones");
 
-template <int R> __device__ __forceinline__ void fft_group(v2d *x, const v2d *tw, unsigned st, unsigned log2n, unsigned N)
+// A workgroup's tile holds B = 2^log2b transforms of N points side by side (index b * N + i); a thread's group of 2^R
+// elements lies inside one transform, and the twiddle index depends on the position inside it only.
+template <int R, int NT>
+__device__ __forceinline__ void fft_group(v2d *x, const v2d *tw, unsigned st, unsigned log2n, unsigned total)
 {
     constexpr unsigned E = 1u << R;
-    const unsigned half = 1u << st;
-    for (unsigned t = threadIdx.x; t < N / E; t += 256) {
-        const unsigned lo = t & (half - 1), base = ((t >> st) << (st + R)) + lo;
+    const unsigned half = 1u << st, per = (1u << log2n) >> R; // groups per transform
+    for (unsigned t = threadIdx.x; t < total / E; t += NT) {
+        const unsigned tb = t >> (log2n - R), tt = t & (per - 1);
+        const unsigned lo = tt & (half - 1), base = (tb << log2n) + ((tt >> st) << (st + R)) + lo;
+        const unsigned fb = fft_pad(base); // bits st .. st + R - 1 of base are clear
         v2d v[E];
 #pragma unroll
-        for (unsigned q = 0; q < E; q++) v[q] = x[fft_pad(base + q * half)];
+        for (unsigned q = 0; q < E; q++) v[q] = x[fb ^ fft_pad(q << st)];
 #pragma unroll
         for (unsigned r = 0; r < (unsigned)R; r++) { // stage st + r pairs the elements whose q differs in bit r
             const unsigned shift = log2n - 1 - st - r;
+            const unsigned fl = fft_twz(lo << shift); // lo < 2^st; the q part of the index lies above it
 #pragma unroll
             for (unsigned q = 0; q < E; q++) {
                 if (q & (1u << r)) continue;
-                const unsigned k = ((q & ((1u << r) - 1)) << st) + lo;
-                const v2d w = tw[k << shift], o = v[q | (1u << r)], e = v[q];
+                const v2d w = tw[fl ^ fft_twz((q & ((1u << r) - 1)) << (st + shift))], o = v[q | (1u << r)], e = v[q];
                 const double tr = w.x * o.x - w.y * o.y, ti = w.x * o.y + w.y * o.x;
                 v[q] = v2d{e.x + tr, e.y + ti};
                 v[q | (1u << r)] = v2d{e.x - tr, e.y - ti};
             }
         }
 #pragma unroll
-        for (unsigned q = 0; q < E; q++) x[fft_pad(base + q * half)] = v[q];
+        for (unsigned q = 0; q < E; q++) x[fb ^ fft_pad(q << st)] = v[q];
     }
     __syncthreads();
 }
 
-// Persistent workgroups: each walks the transforms blockIdx.x, blockIdx.x + gridDim.x, ...; the twiddles are staged
-// once, and the NEXT transform's samples are loaded into registers (PER = ceil(N / 256) <= 16 per thread) before the
-// current one's stages run, so that the load latency is not a phase of its own.
-constexpr unsigned FFT_PER_MAX = SDRX_FFT_MAX / 256;
-
-__global__ __launch_bounds__(256) void fft_kernel(double *iq, const v2d *__restrict__ tw_g, unsigned N, unsigned log2n,
-                                                  size_t pitch, unsigned nchan)
+// Persistent workgroups of NT threads: each walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (a tile = B
+// consecutive rows, so that short transforms still give every thread a group; ONE: B = 1 known at compile time); the
+// twiddles are staged once, and the NEXT tile's samples are loaded into registers (at most SDRX_FFT_MAX / NT per thread)
+// before the current one's stages run, so that the load latency is not a phase of its own.
+template <int NT, bool ONE>
+__global__ __launch_bounds__(NT) void fft_kernel(double *iq, const v2d *__restrict__ tw_g, unsigned log2n, unsigned log2b_,
+                                                 size_t pitch, unsigned nchan)
 {
+    constexpr unsigned PER = SDRX_FFT_MAX / NT;
     extern __shared__ v2d fft_lds[];
+    const unsigned log2b = ONE ? 0 : log2b_;
+    const unsigned N = 1u << log2n, total = N << log2b, ntiles = (nchan + (1u << log2b) - 1) >> log2b;
     v2d *tw = fft_lds, *x = fft_lds + N / 2;
-    for (unsigned j = threadIdx.x; j < N / 2; j += 256) tw[j] = tw_g[j];
-    v2d nxt[FFT_PER_MAX];
-    auto fetch = [&](unsigned row) {
-        const v2d *g = reinterpret_cast<const v2d *>(iq) + (size_t)row * pitch;
+    for (unsigned j = threadIdx.x; j < N / 2; j += NT) tw[fft_twz(j)] = tw_g[j];
+    v2d nxt[PER];
+    auto fetch = [&](unsigned tile) {
+        const v2d *g = reinterpret_cast<const v2d *>(iq) + (size_t)(tile << log2b) * pitch;
 #pragma unroll
-        for (unsigned q = 0; q < FFT_PER_MAX; q++) {
-            const unsigned i = threadIdx.x + 256 * q;
-            if (i < N) nxt[q] = g[i];
+        for (unsigned q = 0; q < PER; q++) {
+            const unsigned i = threadIdx.x + NT * q;
+            if (ONE) {
+                if (i < N) nxt[q] = g[i];
+            } else if (i < total && (tile << log2b) + (i >> log2n) < nchan)
+                nxt[q] = g[(size_t)(i >> log2n) * pitch + (i & (N - 1))];
         }
     };
-    if (blockIdx.x < nchan) fetch(blockIdx.x);
-    for (unsigned row = blockIdx.x; row < nchan; row += gridDim.x) {
-        __syncthreads(); // the previous transform's last reads of x are done (and, the first time, tw is complete)
+    if (blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads(); // the previous tile's last reads of x are done (and, the first time, tw is complete)
 #pragma unroll
-        for (unsigned q = 0; q < FFT_PER_MAX; q++) {
-            const unsigned i = threadIdx.x + 256 * q;
-            if (i < N) x[fft_pad(__brev(i) >> (32 - log2n))] = nxt[q];
+        for (unsigned q = 0; q < PER; q++) {
+            const unsigned i = threadIdx.x + NT * q;
+            if (i < total) x[fft_pad((i & ~(N - 1)) + (__brev(i & (N - 1)) >> (32 - log2n)))] = nxt[q];
         }
-        if (row + gridDim.x < nchan) fetch(row + gridDim.x);
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         __syncthreads();
         unsigned st = 0;
-        for (; st + 3 <= log2n; st += 3) fft_group<3>(x, tw, st, log2n, N);
-        if (log2n - st == 2) fft_group<2>(x, tw, st, log2n, N);
-        if (log2n - st == 1) fft_group<1>(x, tw, st, log2n, N);
-        v2d *g = reinterpret_cast<v2d *>(iq) + (size_t)row * pitch;
-        for (unsigned i = threadIdx.x; i < N; i += 256) g[i] = x[fft_pad(i)];
+        for (; st + 3 <= log2n; st += 3) fft_group<3, NT>(x, tw, st, log2n, total);
+        if (log2n - st == 2) fft_group<2, NT>(x, tw, st, log2n, total);
+        if (log2n - st == 1) fft_group<1, NT>(x, tw, st, log2n, total);
+        v2d *g = reinterpret_cast<v2d *>(iq) + (size_t)(tile << log2b) * pitch;
+        for (unsigned i = threadIdx.x; i < total; i += NT) {
+            if (ONE) g[i] = x[fft_pad(i)];
+            else if ((tile << log2b) + (i >> log2n) < nchan) g[(size_t)(i >> log2n) * pitch + (i & (N - 1))] = x[fft_pad(i)];
+        }
     }
 }
 
@@ -419,7 +442,10 @@ int fft_twiddles(unsigned log2n, hipStream_t s, const v2d **out)
     }
     std::lock_guard<std::mutex> lk(g_fft_mu);
     if (!g_fft_attr[dev]) {
-        SDRX_HIP(hipFuncSetAttribute((const void *)fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const void *inst[] = {(const void *)fft_kernel<256, true>,  (const void *)fft_kernel<512, true>,
+                              (const void *)fft_kernel<1024, true>, (const void *)fft_kernel<256, false>,
+                              (const void *)fft_kernel<512, false>, (const void *)fft_kernel<1024, false>};
+        for (const void *f : inst) SDRX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_fft_attr[dev] = true;
     }
     if (!g_fft_tw[dev][log2n]) {
@@ -590,12 +616,35 @@ extern "C" int sdrx_fft_dev(double *iq, size_t n, size_t nchan, size_t pitch, vo
     const v2d *tw = nullptr;
     int rc = fft_twiddles(log2n, (hipStream_t)stream, &tw);
     if (rc != SDRX_OK) return rc;
-    size_t lds = (n / 2 + n + n / 8 + 1) * sizeof(v2d);
-    // as many workgroups as are resident at once (LDS or the 8-workgroups-of-256 limit per CU), each looping over rows
+    // tile: B = 2^log2b transforms side by side per workgroup, so that short lengths fill the workgroup's threads
+    const Tuning &tn = tuning();
+    // measured (build/fftprobe.py, 2^26 points): lengths >= 1024 run best one transform per workgroup (256 threads; 1024
+    // for 4096 points, whose LDS admits one workgroup per CU), shorter ones as 4096-point tiles under 1024 threads
+    size_t tile = tn.fft_tile > 0 ? (size_t)tn.fft_tile : (n >= 1024 ? n : 4096);
+    if (tile > SDRX_FFT_MAX) tile = SDRX_FFT_MAX;
+    unsigned log2b = 0;
+    while ((n << (log2b + 1)) <= tile && (1ull << (log2b + 1)) <= nchan) log2b++;
+    const size_t total = n << log2b, ntiles = (nchan + (1ull << log2b) - 1) >> log2b;
+    int nt = tn.fft_nt == 256 || tn.fft_nt == 512 || tn.fft_nt == 1024 ? tn.fft_nt : (total >= 4096 ? 1024 : 256);
+    const size_t lds = (n / 2 + total) * sizeof(v2d);
+    // as many workgroups as are resident at once (LDS, or 2048 threads per CU), each looping over its tiles
     size_t per_cu = (160 * 1024) / (lds + 256);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-    const size_t grid = nchan < per_cu * 256 ? nchan : per_cu * 256;
-    fft_kernel<<<(unsigned)grid, 256, lds, (hipStream_t)stream>>>(iq, tw, (unsigned)n, log2n, pitch, (unsigned)nchan);
+    const size_t by_threads = 2048 / (size_t)nt;
+    per_cu = per_cu < 1 ? 1 : (per_cu > by_threads ? by_threads : per_cu);
+    const unsigned grid = (unsigned)(ntiles < per_cu * 256 ? ntiles : per_cu * 256);
+    hipStream_t s = (hipStream_t)stream;
+#define SDRX_FFT_LAUNCH(NT_, ONE_) \
+    fft_kernel<NT_, ONE_><<<grid, NT_, lds, s>>>(iq, tw, log2n, log2b, pitch, (unsigned)nchan)
+    if (log2b == 0) {
+        if (nt == 256) SDRX_FFT_LAUNCH(256, true);
+        else if (nt == 512) SDRX_FFT_LAUNCH(512, true);
+        else SDRX_FFT_LAUNCH(1024, true);
+    } else {
+        if (nt == 256) SDRX_FFT_LAUNCH(256, false);
+        else if (nt == 512) SDRX_FFT_LAUNCH(512, false);
+        else SDRX_FFT_LAUNCH(1024, false);
+    }
+#undef SDRX_FFT_LAUNCH
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
 }

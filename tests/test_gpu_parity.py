@@ -661,6 +661,24 @@ def test_dsp_fft(n):
         assert np.max(np.abs(got[c] - ref)) <= 1e-12 * max(1.0, np.abs(ref).max()) * np.log2(max(n, 2))
 
 
+@pytest.mark.parametrize("n,nchan", [(16, 150001), (256, 9001), (2048, 1100), (4096, 301)])
+def test_dsp_fft_many_rows(n, nchan, tune):
+    """More rows than one pass of the persistent workgroups holds (each walks several tiles; a tile is several short
+    transforms side by side, the last one ragged): rows repeat with period 97, so every row is checked, 97 against the
+    oracle and the rest against their copies; under every workgroup size the library has."""
+    rng = np.random.default_rng(n + nchan)
+    base = rng.normal(0, 1, (97, n)) + 1j * rng.normal(0, 1, (97, n))
+    want = np.stack([O.fft(base[c], O.MATH_SHARED) for c in range(97)])
+    zb = torch.tensor(base, device="cuda")
+    idx = torch.arange(nchan, device="cuda") % 97
+    for nt in (0, 256, 512, 1024):
+        tune("SDRX_FFT_NT", nt)
+        zd = zb[idx].contiguous()
+        device.fft(zd)
+        assert np.array_equal(zd[:97].cpu().numpy(), want), nt
+        assert torch.equal(torch.view_as_real(zd), torch.view_as_real(zd[:97][idx].contiguous())), nt
+
+
 def test_dsp_unsupported_and_empty():
     z = torch.zeros(2, 12, dtype=torch.complex128, device="cuda")
     with pytest.raises(RuntimeError):
