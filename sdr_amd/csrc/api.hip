@@ -67,6 +67,7 @@ Tuning &tuning()
         x.iir_cw = env_int("SDRX_IIR_CW", d.iir_cw);
         x.fft_nt = env_int("SDRX_FFT_NT", d.fft_nt);
         x.fft_tile = env_int("SDRX_FFT_TILE", d.fft_tile);
+        x.fft_ct = env_int("SDRX_FFT_CT", d.fft_ct);
         return x;
     }();
     return t;
@@ -170,6 +171,7 @@ extern "C" int sdrx_tune(const char *name, const char *value)
     else if (strcmp(name, "SDRX_IIR_CW") == 0) t.iir_cw = dflt ? d.iir_cw : v;
     else if (strcmp(name, "SDRX_FFT_NT") == 0) t.fft_nt = dflt ? d.fft_nt : v;
     else if (strcmp(name, "SDRX_FFT_TILE") == 0) t.fft_tile = dflt ? d.fft_tile : v;
+    else if (strcmp(name, "SDRX_FFT_CT") == 0) t.fft_ct = dflt ? d.fft_ct : v;
     else {
         set_error("sdrx_tune: unknown switch %s", name);
         return SDRX_EINVAL;

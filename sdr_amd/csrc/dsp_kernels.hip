@@ -380,14 +380,16 @@ __device__ __forceinline__ void fft_group(v2d *x, const v2d *tw, unsigned st, un
 // Persistent workgroups of NT threads: each walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (a tile = B
 // consecutive rows, so that short transforms still give every thread a group; ONE: B = 1 known at compile time); the
 // twiddles are staged once, and the NEXT tile's samples are loaded into registers (at most SDRX_FFT_MAX / NT per thread)
-// before the current one's stages run, so that the load latency is not a phase of its own.
-template <int NT, bool ONE>
-__global__ __launch_bounds__(NT) void fft_kernel(double *iq, const v2d *__restrict__ tw_g, unsigned log2n, unsigned log2b_,
+// before the current one's stages run, so that the load latency is not a phase of its own.  L2 != 0: log2 N known at
+// compile time (every stride, shift and folded constant becomes an immediate); L2 == 0: any length.  Whole-transform
+// tiles stream their rows with nontemporal accesses (measured: 2-4 % faster there, 7 % slower on tiles of short rows).
+template <int NT, bool ONE, int L2>
+__global__ __launch_bounds__(NT) void fft_kernel(double *iq, const v2d *__restrict__ tw_g, unsigned log2n_, unsigned log2b_,
                                                  size_t pitch, unsigned nchan)
 {
     constexpr unsigned PER = SDRX_FFT_MAX / NT;
     extern __shared__ v2d fft_lds[];
-    const unsigned log2b = ONE ? 0 : log2b_;
+    const unsigned log2n = L2 ? (unsigned)L2 : log2n_, log2b = ONE ? 0 : log2b_;
     const unsigned N = 1u << log2n, total = N << log2b, ntiles = (nchan + (1u << log2b) - 1) >> log2b;
     v2d *tw = fft_lds, *x = fft_lds + N / 2;
     for (unsigned j = threadIdx.x; j < N / 2; j += NT) tw[fft_twz(j)] = tw_g[j];
@@ -398,29 +400,48 @@ __global__ __launch_bounds__(NT) void fft_kernel(double *iq, const v2d *__restri
         for (unsigned q = 0; q < PER; q++) {
             const unsigned i = threadIdx.x + NT * q;
             if (ONE) {
-                if (i < N) nxt[q] = g[i];
+                if (i < N) nxt[q] = DSP_LOAD(g + i);
             } else if (i < total && (tile << log2b) + (i >> log2n) < nchan)
                 nxt[q] = g[(size_t)(i >> log2n) * pitch + (i & (N - 1))];
         }
+    };
+    // element q of this thread is index i = threadIdx.x + NT * q of the tile.  Where NT <= N the two terms share no
+    // bits, neither before nor after the bit reversal inside the transform, so the fold of each is taken apart: the
+    // thread's own once, the q part on the scalar unit.
+    const bool split = NT <= N;
+    const unsigned own_fwd = fft_pad(threadIdx.x), own_rev = fft_pad(__brev(threadIdx.x) >> (32 - log2n));
+    auto slot_rev = [&](unsigned q) { // where element q goes: bit-reversed inside its transform
+        const unsigned hi = NT * q;
+        if (split) return own_rev ^ fft_pad((hi & ~(N - 1)) + (__brev(hi & (N - 1)) >> (32 - log2n)));
+        const unsigned i = threadIdx.x + hi;
+        return fft_pad((i & ~(N - 1)) + (__brev(i & (N - 1)) >> (32 - log2n)));
     };
     if (blockIdx.x < ntiles) fetch(blockIdx.x);
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads(); // the previous tile's last reads of x are done (and, the first time, tw is complete)
 #pragma unroll
-        for (unsigned q = 0; q < PER; q++) {
-            const unsigned i = threadIdx.x + NT * q;
-            if (i < total) x[fft_pad((i & ~(N - 1)) + (__brev(i & (N - 1)) >> (32 - log2n)))] = nxt[q];
-        }
+        for (unsigned q = 0; q < PER; q++)
+            if (threadIdx.x + NT * q < total) x[slot_rev(q)] = nxt[q];
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         __syncthreads();
-        unsigned st = 0;
-        for (; st + 3 <= log2n; st += 3) fft_group<3, NT>(x, tw, st, log2n, total);
-        if (log2n - st == 2) fft_group<2, NT>(x, tw, st, log2n, total);
-        if (log2n - st == 1) fft_group<1, NT>(x, tw, st, log2n, total);
+        if (L2) {
+#pragma unroll
+            for (unsigned st = 0; st + 3 <= (unsigned)L2; st += 3) fft_group<3, NT>(x, tw, st, L2, total);
+            if (L2 % 3 == 2) fft_group<2, NT>(x, tw, L2 - 2, L2, total);
+            if (L2 % 3 == 1) fft_group<1, NT>(x, tw, L2 - 1, L2, total);
+        } else {
+            unsigned st = 0;
+            for (; st + 3 <= log2n; st += 3) fft_group<3, NT>(x, tw, st, log2n, total);
+            if (log2n - st == 2) fft_group<2, NT>(x, tw, st, log2n, total);
+            if (log2n - st == 1) fft_group<1, NT>(x, tw, st, log2n, total);
+        }
         v2d *g = reinterpret_cast<v2d *>(iq) + (size_t)(tile << log2b) * pitch;
-        for (unsigned i = threadIdx.x; i < total; i += NT) {
-            if (ONE) g[i] = x[fft_pad(i)];
-            else if ((tile << log2b) + (i >> log2n) < nchan) g[(size_t)(i >> log2n) * pitch + (i & (N - 1))] = x[fft_pad(i)];
+        for (unsigned hi = 0; hi < total; hi += NT) {
+            const unsigned i = threadIdx.x + hi;
+            if (i >= total) break;
+            const v2d v = x[own_fwd ^ fft_pad(hi)]; // hi has no bit below NT: fft_pad(i) taken apart
+            if (ONE) DSP_STORE(v, g + i);
+            else if ((tile << log2b) + (i >> log2n) < nchan) g[(size_t)(i >> log2n) * pitch + (i & (N - 1))] = v;
         }
     }
 }
@@ -442,9 +463,13 @@ int fft_twiddles(unsigned log2n, hipStream_t s, const v2d **out)
     }
     std::lock_guard<std::mutex> lk(g_fft_mu);
     if (!g_fft_attr[dev]) {
-        const void *inst[] = {(const void *)fft_kernel<256, true>,  (const void *)fft_kernel<512, true>,
-                              (const void *)fft_kernel<1024, true>, (const void *)fft_kernel<256, false>,
-                              (const void *)fft_kernel<512, false>, (const void *)fft_kernel<1024, false>};
+        const void *inst[] = {(const void *)fft_kernel<256, true, 0>,   (const void *)fft_kernel<512, true, 0>,
+                              (const void *)fft_kernel<1024, true, 0>,  (const void *)fft_kernel<256, false, 0>,
+                              (const void *)fft_kernel<512, false, 0>,  (const void *)fft_kernel<1024, false, 0>,
+                              (const void *)fft_kernel<256, true, 10>,  (const void *)fft_kernel<256, true, 11>,
+                              (const void *)fft_kernel<1024, true, 12>, (const void *)fft_kernel<1024, false, 6>,
+                              (const void *)fft_kernel<1024, false, 7>, (const void *)fft_kernel<1024, false, 8>,
+                              (const void *)fft_kernel<1024, false, 9>};
         for (const void *f : inst) SDRX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_fft_attr[dev] = true;
     }
@@ -633,16 +658,24 @@ extern "C" int sdrx_fft_dev(double *iq, size_t n, size_t nchan, size_t pitch, vo
     per_cu = per_cu < 1 ? 1 : (per_cu > by_threads ? by_threads : per_cu);
     const unsigned grid = (unsigned)(ntiles < per_cu * 256 ? ntiles : per_cu * 256);
     hipStream_t s = (hipStream_t)stream;
-#define SDRX_FFT_LAUNCH(NT_, ONE_) \
-    fft_kernel<NT_, ONE_><<<grid, NT_, lds, s>>>(iq, tw, log2n, log2b, pitch, (unsigned)nchan)
+#define SDRX_FFT_LAUNCH(NT_, ONE_, L2_) \
+    fft_kernel<NT_, ONE_, L2_><<<grid, NT_, lds, s>>>(iq, tw, log2n, log2b, pitch, (unsigned)nchan)
+    const bool ct = tn.fft_ct != 0; // compile-time lengths: the default shapes of 64 ... 4096 points
     if (log2b == 0) {
-        if (nt == 256) SDRX_FFT_LAUNCH(256, true);
-        else if (nt == 512) SDRX_FFT_LAUNCH(512, true);
-        else SDRX_FFT_LAUNCH(1024, true);
+        if (ct && nt == 256 && log2n == 10) SDRX_FFT_LAUNCH(256, true, 10);
+        else if (ct && nt == 256 && log2n == 11) SDRX_FFT_LAUNCH(256, true, 11);
+        else if (ct && nt == 1024 && log2n == 12) SDRX_FFT_LAUNCH(1024, true, 12);
+        else if (nt == 256) SDRX_FFT_LAUNCH(256, true, 0);
+        else if (nt == 512) SDRX_FFT_LAUNCH(512, true, 0);
+        else SDRX_FFT_LAUNCH(1024, true, 0);
     } else {
-        if (nt == 256) SDRX_FFT_LAUNCH(256, false);
-        else if (nt == 512) SDRX_FFT_LAUNCH(512, false);
-        else SDRX_FFT_LAUNCH(1024, false);
+        if (ct && nt == 1024 && log2n == 6) SDRX_FFT_LAUNCH(1024, false, 6);
+        else if (ct && nt == 1024 && log2n == 7) SDRX_FFT_LAUNCH(1024, false, 7);
+        else if (ct && nt == 1024 && log2n == 8) SDRX_FFT_LAUNCH(1024, false, 8);
+        else if (ct && nt == 1024 && log2n == 9) SDRX_FFT_LAUNCH(1024, false, 9);
+        else if (nt == 256) SDRX_FFT_LAUNCH(256, false, 0);
+        else if (nt == 512) SDRX_FFT_LAUNCH(512, false, 0);
+        else SDRX_FFT_LAUNCH(1024, false, 0);
     }
 #undef SDRX_FFT_LAUNCH
     SDRX_HIP(hipGetLastError());

@@ -661,7 +661,7 @@ def test_dsp_fft(n):
         assert np.max(np.abs(got[c] - ref)) <= 1e-12 * max(1.0, np.abs(ref).max()) * np.log2(max(n, 2))
 
 
-@pytest.mark.parametrize("n,nchan", [(16, 150001), (256, 9001), (2048, 1100), (4096, 301)])
+@pytest.mark.parametrize("n,nchan", [(16, 150001), (64, 40001), (128, 3), (256, 9001), (512, 5001), (1024, 2100), (2048, 1100), (4096, 301)])
 def test_dsp_fft_many_rows(n, nchan, tune):
     """More rows than one pass of the persistent workgroups holds (each walks several tiles; a tile is several short
     transforms side by side, the last one ragged): rows repeat with period 97, so every row is checked, 97 against the
@@ -671,12 +671,14 @@ def test_dsp_fft_many_rows(n, nchan, tune):
     want = np.stack([O.fft(base[c], O.MATH_SHARED) for c in range(97)])
     zb = torch.tensor(base, device="cuda")
     idx = torch.arange(nchan, device="cuda") % 97
-    for nt in (0, 256, 512, 1024):
+    for nt, ct in ((0, 1), (0, 0), (256, 0), (512, 0), (1024, 0)):  # ct: compile-time-length instances on / off
         tune("SDRX_FFT_NT", nt)
+        tune("SDRX_FFT_CT", ct)
         zd = zb[idx].contiguous()
         device.fft(zd)
-        assert np.array_equal(zd[:97].cpu().numpy(), want), nt
-        assert torch.equal(torch.view_as_real(zd), torch.view_as_real(zd[:97][idx].contiguous())), nt
+        m = min(97, nchan)
+        assert np.array_equal(zd[:m].cpu().numpy(), want[:m]), (nt, ct)
+        assert torch.equal(torch.view_as_real(zd), torch.view_as_real(zd[:m][idx].contiguous())), (nt, ct)
 
 
 def test_dsp_unsupported_and_empty():
