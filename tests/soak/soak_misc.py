@@ -42,6 +42,8 @@ def one_round():
     cases.append(("normalize", lambda: T.test_dsp_normalize_bit_exact(log_uniform(1, 20000), float(np.exp(pick.uniform(-3, 6))),
                                                                       float(pick.uniform(0, 300)))))
     cases.append(("fft", lambda: T.test_dsp_fft(1 << r(0, 12))))
+    nf = 1 << r(1, 12)
+    cases.append(("fft_many_rows", lambda: T.test_dsp_fft_many_rows(nf, log_uniform(1, max(1, (1 << 22) // nf)), tune)))
     cases.append(("modulators", T.test_am_fm_modulator_kernels_vs_oracle))
     cases.append(("psk_modulators", T.test_psk_modulators_vs_oracle))
     cases.append(("fm_convolve", T.test_fm_convolve_vs_oracle_and_demodulate_identity))
@@ -54,7 +56,7 @@ def one_round():
             print("FAILED in", name, flush=True)
             raise
         finally:
-            for sw in ("SDRX_IIR_CW", "SDRX_FSK_ROWS"):
+            for sw in ("SDRX_IIR_CW", "SDRX_FSK_ROWS", "SDRX_FFT_NT", "SDRX_FFT_CT"):
                 _lib.lib().sdrx_tune(sw.encode(), None)
 
 
