@@ -338,7 +338,7 @@ __global__ void fft_twiddle_kernel(v2d *tw, unsigned N)
 // the lowest by xor -- a bijection that needs no spare slots and leaves the bit-reversed scatter, every stage group's
 // strided reads and writes, and the final row read (nearly) conflict-free.  Twiddles: the same with hexadecimal digits,
 // so that the multiples of 2^m a stage reads spread over all 16 banks (they sat on one: 21 LDS cycles per read instead of
-// 4; build/fft_lds_sim.py models every access).  Both folds are linear over xor: fold(a + b) = fold(a) ^ fold(b) where a
+// 4; profiles/probes/fft_lds_sim.py models every access).  Both folds are linear over xor: fold(a + b) = fold(a) ^ fold(b) where a
 // and b share no bits, which lets the wave-uniform part of an index be folded on the scalar unit.
 __device__ __forceinline__ unsigned fft_pad(unsigned i) { return i ^ ((i >> 3) & 7) ^ ((i >> 6) & 7) ^ ((i >> 9) & 7); }
 __device__ __forceinline__ unsigned fft_twz(unsigned j) { return j ^ ((j >> 4) & 15) ^ ((j >> 8) & 15); }
@@ -643,7 +643,7 @@ extern "C" int sdrx_fft_dev(double *iq, size_t n, size_t nchan, size_t pitch, vo
     if (rc != SDRX_OK) return rc;
     // tile: B = 2^log2b transforms side by side per workgroup, so that short lengths fill the workgroup's threads
     const Tuning &tn = tuning();
-    // measured (build/fftprobe.py, 2^26 points): lengths >= 1024 run best one transform per workgroup (256 threads; 1024
+    // measured (profiles/probes/fftprobe.py, 2^26 points): lengths >= 1024 run best one transform per workgroup (256 threads; 1024
     // for 4096 points, whose LDS admits one workgroup per CU), shorter ones as 4096-point tiles under 1024 threads
     size_t tile = tn.fft_tile > 0 ? (size_t)tn.fft_tile : (n >= 1024 ? n : 4096);
     if (tile > SDRX_FFT_MAX) tile = SDRX_FFT_MAX;
