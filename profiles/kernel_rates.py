@@ -128,6 +128,18 @@ for name, fn, bytes_per in (("iir dc_block", lambda: device.iir(device.IIR_DC_BL
     rows.append({"kernel": name + " (16384 rows x 2^13)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
                  "algorithmic_GBps": bytes_per * tot / t / 1e9, "frac_of_8TBps": bytes_per * tot / t / 1e9 / PEAK})
 del x
+# the recurrences on a bank with more, shorter rows (8 waves per SIMD instead of one)
+x = torch.randn(131072, 1024, dtype=torch.float64, device=dev) * 50
+st2 = torch.zeros(131072, 4, dtype=torch.float64, device=dev)
+for name, fn in (("iir dc_block", lambda: device.iir(device.IIR_DC_BLOCK, 0.995, x)),
+                 ("iir lowpass1", lambda: device.iir(device.IIR_LOWPASS, 0.06, x, state=st2)),
+                 ("iir notch", lambda: device.iir(device.IIR_NOTCH, coef, x, state=st2)),
+                 ("iir integrate", lambda: device.iir(device.IIR_INTEGRATE, 1e-9, x))):
+    t = timed(fn, iters=10, warm=2)
+    tot = x.numel()
+    rows.append({"kernel": name + " (131072 rows x 2^10)", "samples": tot, "ms": t * 1e3, "Msamples_per_s": tot / t / 1e6,
+                 "algorithmic_GBps": 16.0 * tot / t / 1e9, "frac_of_8TBps": 16.0 * tot / t / 1e9 / PEAK})
+del x, st2
 for nfft in (64, 256, 1024, 4096):  # the other lengths, same 2^26 points
     z = z.view(-1, nfft)
     t = timed(lambda: device.fft(z), iters=10, warm=2)

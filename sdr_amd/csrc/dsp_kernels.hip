@@ -31,6 +31,7 @@ struct IirCoef {
 };
 
 enum { K_DC = SDRX_IIR_DC_BLOCK, K_LP = SDRX_IIR_LOWPASS, K_NOTCH = SDRX_IIR_NOTCH, K_INT = SDRX_IIR_INTEGRATE };
+constexpr int K_DCA = 100; // the DC blocker called in place (an instance of its own: no per-sample select on the call's kind)
 
 // samples that need their index looked at before the recurrence is in its steady form
 template <int KIND> constexpr int iir_prologue() { return KIND == K_NOTCH ? 2 : (KIND == K_LP ? 0 : 1); }
@@ -39,15 +40,15 @@ template <int KIND> __device__ __forceinline__ double iir_first(double x, double
 {
     // DC_Filter: output[0] = input[0]; integrate: array[0] stays; notch: samples 0 and 1 stay
     // and do not enter the delay line.
-    if (KIND == K_DC) s[0] = x, s[1] = x;
+    if (KIND == K_DC || KIND == K_DCA) s[0] = x, s[1] = x;
     if (KIND == K_INT) s[0] = x;
     return x;
 }
 
 template <int KIND> __device__ __forceinline__ double iir_step(double x, double (&s)[4], const IirCoef &k)
 {
-    if (KIND == K_DC) { // y(n) = x(n) - x(n-1) + R*y(n-1); in place (c[1] != 0) input[i-1] has already been overwritten
-        const double xp = k.c[1] != 0.0 ? s[1] : s[0]; // by output[i-1] when the reference reads it (DC_Filter.cpp:18)
+    if (KIND == K_DC || KIND == K_DCA) { // y(n) = x(n) - x(n-1) + R*y(n-1); in place (K_DCA) input[i-1] has already been
+        const double xp = KIND == K_DCA ? s[1] : s[0]; // overwritten by output[i-1] when the reference reads it (DC_Filter.cpp:18)
         double y = x - xp + k.c[0] * s[1];
         s[0] = x, s[1] = y;
         return y;
@@ -114,19 +115,30 @@ __global__ __launch_bounds__(64) void iir_kernel(const double *x, double *y, siz
         for (int j = 0; j < 4; j++) s[j] = state[c * 4 + j];
     // load/store role of this lane: rows c0 + 4i + sub (i < NI), sample s0 + col
     const size_t row0 = (c0 + sub) * pitch + col;
-    double nxt[NI];
-    auto load = [&](size_t s0) {
+    // a wave whose CW rows all exist moves its full chunks through wave-uniform row pointers plus one lane offset: no
+    // per-access predicate, no per-lane 64-bit address (the kernel is bound by the instructions a wave issues)
+    const bool rows_full = RPI == 1 && c0 + CW <= nchan;
+    const double *xb = x + c0 * pitch;
+    double *yb = y + c0 * pitch;
+    auto load = [&](double (&nxt)[NI], size_t s0) {
+        if (rows_full && s0 + IC <= n) {
+            const double *p = xb + s0;
+#pragma unroll
+            for (int i = 0; i < NI; i++) nxt[i] = DSP_LOAD(p + (size_t)i * pitch + l);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NI; i++)
             nxt[i] = (RPI * i + sub < CW && c0 + RPI * i + sub < nchan && s0 + col < n) ? DSP_LOAD(x + row0 + (size_t)(RPI * i) * pitch + s0) : 0.0;
     };
-    load(0);
-    for (size_t s0 = 0; s0 < n; s0 += IC) {
+    // one chunk: its samples (loaded two chunks ago into nxt) go to the tile, the chunk two ahead is requested into the
+    // same registers -- with one wave per SIMD the loads of ONE chunk in flight (CW x 512 bytes) do not cover the HBM latency
+    auto chunk = [&](double (&nxt)[NI], size_t s0) {
 #pragma unroll
         for (int i = 0; i < NI; i++)
             if (RPI * i + sub < CW) tile[(RPI * i + sub) * IPITCH + col] = nxt[i];
         wave_lds_sync();
-        if (s0 + IC < n) load(s0 + IC);
+        if (s0 + 2 * IC < n) load(nxt, s0 + 2 * IC);
         double v[IC];
 #pragma unroll
         for (int j = 0; j < IC; j++) v[j] = tile[cl * IPITCH + j];
@@ -138,10 +150,23 @@ __global__ __launch_bounds__(64) void iir_kernel(const double *x, double *y, siz
             for (int j = 0; j < IC; j++) tile[cl * IPITCH + j] = v[j];
         }
         wave_lds_sync();
+        if (rows_full && s0 + IC <= n) {
+            double *p = yb + s0;
 #pragma unroll
-        for (int i = 0; i < NI; i++)
-            if (RPI * i + sub < CW && c0 + RPI * i + sub < nchan && s0 + col < n) DSP_STORE(tile[(RPI * i + sub) * IPITCH + col], y + row0 + (size_t)(RPI * i) * pitch + s0);
+            for (int i = 0; i < NI; i++) DSP_STORE(tile[i * IPITCH + l], p + (size_t)i * pitch + l);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+                if (RPI * i + sub < CW && c0 + RPI * i + sub < nchan && s0 + col < n) DSP_STORE(tile[(RPI * i + sub) * IPITCH + col], y + row0 + (size_t)(RPI * i) * pitch + s0);
+        }
         wave_lds_sync();
+    };
+    double nxt_a[NI], nxt_b[NI];
+    load(nxt_a, 0);
+    if (IC < n) load(nxt_b, IC);
+    for (size_t s0 = 0; s0 < n; s0 += 2 * IC) {
+        chunk(nxt_a, s0);
+        if (s0 + IC < n) chunk(nxt_b, s0 + IC);
     }
     if (carried && l < CW)
         for (int j = 0; j < 4; j++) state[c * 4 + j] = s[j];
@@ -531,13 +556,16 @@ extern "C" int sdrx_iir_dev(int kind, const double *coef, const double *x, doubl
     }
     IirCoef k = {{0, 0, 0, 0, 0}};
     for (int j = 0; j < ncoef[kind]; j++) k.c[j] = coef[j];
-    if (kind == K_DC && (const double *)y == x) k.c[1] = 1.0; // aliased call: the reference's own in-place behaviour
+    const bool aliased = kind == K_DC && (const double *)y == x; // aliased call: the reference's own in-place behaviour
     // rows per wave: 16 once that gives every SIMD of the part (1024) a wave, else 4 (64 only on request)
     int cw = nchan >= 16 * 1024 ? 16 : 4;
     if (const int v = tuning().iir_cw; v == 64 || v == 16 || v == 4) cw = v;
     hipStream_t s = (hipStream_t)stream;
     switch (kind) {
-    case K_DC: launch_iir<K_DC>(cw, x, y, n, nchan, pitch, k, state, s); break;
+    case K_DC:
+        if (aliased) launch_iir<K_DCA>(cw, x, y, n, nchan, pitch, k, state, s);
+        else launch_iir<K_DC>(cw, x, y, n, nchan, pitch, k, state, s);
+        break;
     case K_LP: launch_iir<K_LP>(cw, x, y, n, nchan, pitch, k, state, s); break;
     case K_NOTCH: launch_iir<K_NOTCH>(cw, x, y, n, nchan, pitch, k, state, s); break;
     default: launch_iir<K_INT>(cw, x, y, n, nchan, pitch, k, state, s); break;
