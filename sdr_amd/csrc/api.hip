@@ -65,6 +65,7 @@ Tuning &tuning()
         x.psk_pieces = env_int("SDRX_PSK_PIECES", d.psk_pieces);
         x.fsk_rows = env_int("SDRX_FSK_ROWS", d.fsk_rows);
         x.iir_cw = env_int("SDRX_IIR_CW", d.iir_cw);
+        x.iir_pair = env_int("SDRX_IIR_PAIR", d.iir_pair);
         x.fft_nt = env_int("SDRX_FFT_NT", d.fft_nt);
         x.fft_tile = env_int("SDRX_FFT_TILE", d.fft_tile);
         x.fft_ct = env_int("SDRX_FFT_CT", d.fft_ct);
@@ -169,6 +170,7 @@ extern "C" int sdrx_tune(const char *name, const char *value)
     else if (strcmp(name, "SDRX_PSK_PIECES") == 0) t.psk_pieces = dflt ? d.psk_pieces : v;
     else if (strcmp(name, "SDRX_FSK_ROWS") == 0) t.fsk_rows = dflt ? d.fsk_rows : v;
     else if (strcmp(name, "SDRX_IIR_CW") == 0) t.iir_cw = dflt ? d.iir_cw : v;
+    else if (strcmp(name, "SDRX_IIR_PAIR") == 0) t.iir_pair = dflt ? d.iir_pair : v;
     else if (strcmp(name, "SDRX_FFT_NT") == 0) t.fft_nt = dflt ? d.fft_nt : v;
     else if (strcmp(name, "SDRX_FFT_TILE") == 0) t.fft_tile = dflt ? d.fft_tile : v;
     else if (strcmp(name, "SDRX_FFT_CT") == 0) t.fft_ct = dflt ? d.fft_ct : v;

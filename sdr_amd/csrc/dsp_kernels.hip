@@ -172,11 +172,115 @@ __global__ __launch_bounds__(64) void iir_kernel(const double *x, double *y, siz
         for (int j = 0; j < 4; j++) state[c * 4 + j] = s[j];
 }
 
+// Two-wave form for banks that give a SIMD no more than one wave (a lone wave issues an instruction per ~8 cycles, and
+// the chain is a quarter of what a chunk costs it): the two waves of a workgroup share CW rows and take the chunks in
+// turn.  In round r the wave r % 2 runs the chain of chunk r (state handed over through LDS) while the other one
+// writes back chunk r - 1, which it ran the round before, and stages chunk r + 1, its next; one s_barrier per round,
+// the same count for both waves.  Same arithmetic in the same order per row: bit-identical to iir_kernel.
+template <int KIND, int CW>
+__global__ __launch_bounds__(128) void iir_pair_kernel(const double *x, double *y, size_t n, size_t nchan, size_t pitch, IirCoef k,
+                                                       double *state)
+{
+    static_assert(RPI == 1, "one row per load instruction");
+    constexpr int NI = CW;
+    __shared__ double tiles[2][CW * IPITCH];
+    __shared__ double hand[CW][4];
+    const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63, cl = l % CW;
+    double *tile = tiles[w];
+    const size_t c0 = (size_t)blockIdx.x * CW, c = c0 + cl;
+    double s[4] = {0, 0, 0, 0};
+    const bool carried = (KIND == K_LP || KIND == K_NOTCH) && state != nullptr && c < nchan;
+    if (carried)
+        for (int j = 0; j < 4; j++) s[j] = state[c * 4 + j];
+    const bool rows_full = c0 + CW <= nchan;
+    const double *xb = x + c0 * pitch;
+    double *yb = y + c0 * pitch;
+    const size_t nchunks = (n + IC - 1) / IC;
+    double nxt[NI], v[IC];
+    auto load = [&](size_t ch) {
+        const size_t s0 = ch * IC;
+        if (ch >= nchunks) return;
+        if (rows_full && s0 + IC <= n) {
+            const double *p = xb + s0;
+#pragma unroll
+            for (int i = 0; i < NI; i++) nxt[i] = DSP_LOAD(p + (size_t)i * pitch + l);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) nxt[i] = (c0 + i < nchan && s0 + l < n) ? DSP_LOAD(xb + (size_t)i * pitch + s0 + l) : 0.0;
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; i++) tile[i * IPITCH + l] = nxt[i];
+        wave_lds_sync();
+    };
+    if (w == 0) { // wave 0 runs chunk 0 in round 0: staged here; wave 1 stages chunk 1 during round 0
+        load(0);
+        if (nchunks > 0) stage();
+        load(2);
+    } else {
+        load(1);
+    }
+    for (size_t r = 0; r < nchunks + 1; r++) {
+        if ((r & 1) == w) {
+            if (r < nchunks) {
+                const size_t s0 = r * IC;
+                if (r > 0)
+                    for (int j = 0; j < 4; j++) s[j] = hand[cl][j];
+#pragma unroll
+                for (int j = 0; j < IC; j++) v[j] = tile[cl * IPITCH + j];
+                if (s0 + IC <= n) iir_chunk<KIND, false>(v, s, k, s0, n);
+                else iir_chunk<KIND, true>(v, s, k, s0, n);
+                if (l < CW)
+                    for (int j = 0; j < 4; j++) hand[cl][j] = s[j];
+            }
+        } else {
+            if (r >= 1) { // chunk r - 1: this wave ran it in the round before, its results are in v
+                const size_t s0 = (r - 1) * IC;
+                wave_lds_sync();
+                if (l < CW) {
+#pragma unroll
+                    for (int j = 0; j < IC; j++) tile[cl * IPITCH + j] = v[j];
+                }
+                wave_lds_sync();
+                if (rows_full && s0 + IC <= n) {
+                    double *p = yb + s0;
+#pragma unroll
+                    for (int i = 0; i < NI; i++) DSP_STORE(tile[i * IPITCH + l], p + (size_t)i * pitch + l);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NI; i++)
+                        if (c0 + i < nchan && s0 + l < n) DSP_STORE(tile[i * IPITCH + l], yb + (size_t)i * pitch + s0 + l);
+                }
+                wave_lds_sync();
+            }
+            if (r + 1 < nchunks) { // chunk r + 1 waits in nxt
+                stage();
+                load(r + 3);
+            }
+        }
+        __syncthreads();
+    }
+    if (carried && w == 0 && l < CW) {
+        if (nchunks > 0)
+            for (int j = 0; j < 4; j++) s[j] = hand[cl][j];
+        for (int j = 0; j < 4; j++) state[c * 4 + j] = s[j];
+    }
+}
+
 template <int KIND>
 void launch_iir(int cw, const double *x, double *y, size_t n, size_t nchan, size_t pitch, const IirCoef &k, double *state,
                 hipStream_t s)
 {
     dim3 grid((unsigned)((nchan + cw - 1) / cw)), block(64);
+    // two-wave form: where its two waves per row group still find a SIMD each (1024 SIMDs), rows of several chunks.  Measured
+    // (DC blocker / notch, ms): 1024 rows x 2^17 2.61 / 4.61 -> 1.71 / 3.16; 16384 x 2^13 (1024 row groups) 0.46 / 0.46 -> 0.50 / 0.55
+    const int pair = tuning().iir_pair;
+    if (cw != 64 && (pair == 1 || (pair < 0 && grid.x <= 512 && n > 2 * (size_t)IC))) {
+        if (cw == 16) iir_pair_kernel<KIND, 16><<<grid, dim3(128), 0, s>>>(x, y, n, nchan, pitch, k, state);
+        else iir_pair_kernel<KIND, 4><<<grid, dim3(128), 0, s>>>(x, y, n, nchan, pitch, k, state);
+        return;
+    }
     if (cw == 64) iir_kernel<KIND, 64><<<grid, block, 0, s>>>(x, y, n, nchan, pitch, k, state);
     else if (cw == 16) iir_kernel<KIND, 16><<<grid, block, 0, s>>>(x, y, n, nchan, pitch, k, state);
     else iir_kernel<KIND, 4><<<grid, block, 0, s>>>(x, y, n, nchan, pitch, k, state);

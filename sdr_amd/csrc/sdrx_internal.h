@@ -46,6 +46,7 @@ struct Tuning {
     int psk_pieces = 4;       // SDRX_PSK_PIECES: pieces a call is cut into by the block pipeline (2..16)
     int psk_overlap = -1;     // SDRX_PSK_OVERLAP: -1 auto, 0 one stream, 1 block pipeline on two streams
     int iir_cw = 0;           // SDRX_IIR_CW: rows per wave of the recurrences (0 = by bank size)
+    int iir_pair = -1;        // SDRX_IIR_PAIR: -1 auto, 0 one wave per row group, 1 the two-wave form of the recurrences
     int fft_nt = 0;           // SDRX_FFT_NT: threads per fft workgroup (0 = by length; 256, 512, 1024)
     int fft_ct = 1;           // SDRX_FFT_CT: 0 = never use the compile-time-length instances of the fft kernel
     int fft_tile = 0;         // SDRX_FFT_TILE: points per fft workgroup tile = transforms x length (0 = by length)

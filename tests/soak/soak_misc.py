@@ -38,7 +38,7 @@ def one_round():
     cases.append(("fifth_block", lambda: T.test_dsp_fifth_order_block_overload_bit_exact(log_uniform(1, 40000), 1 << r(0, 4))))
     cases.append(("confidence", lambda: T.test_ones_zeros_confidence_walk(log_uniform(1, 400000))))
     cases.append(("confidence_segments", lambda: T.test_ones_zeros_confidence_walk_in_segments(r(1, 12), r(262144, 1500000))))
-    cases.append(("iir", lambda: T.test_dsp_recurrences_bit_exact(log_uniform(1, 9000), [4, 16, 64][r(0, 2)], tune)))
+    cases.append(("iir", lambda: T.test_dsp_recurrences_bit_exact(log_uniform(1, 9000), [4, 16, 64, -4, -16][r(0, 4)], tune)))
     cases.append(("normalize", lambda: T.test_dsp_normalize_bit_exact(log_uniform(1, 20000), float(np.exp(pick.uniform(-3, 6))),
                                                                       float(pick.uniform(0, 300)))))
     cases.append(("fft", lambda: T.test_dsp_fft(1 << r(0, 12))))
@@ -56,7 +56,7 @@ def one_round():
             print("FAILED in", name, flush=True)
             raise
         finally:
-            for sw in ("SDRX_IIR_CW", "SDRX_FSK_ROWS", "SDRX_FFT_NT", "SDRX_FFT_CT"):
+            for sw in ("SDRX_IIR_CW", "SDRX_IIR_PAIR", "SDRX_FSK_ROWS", "SDRX_FFT_NT", "SDRX_FFT_CT"):
                 _lib.lib().sdrx_tune(sw.encode(), None)
 
 

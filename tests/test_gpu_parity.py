@@ -544,13 +544,14 @@ def test_ones_zeros_confidence_walk_under_stream_capture():
 
 # =============================================================================== DSP primitives
 
-@pytest.mark.parametrize("cw", [4, 16, 64])
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 15, 16, 17, 18, 33, 1000, 4099])
+@pytest.mark.parametrize("cw", [4, 16, 64, -4, -16])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 15, 16, 17, 18, 33, 63, 64, 65, 128, 129, 200, 1000, 4099])
 def test_dsp_recurrences_bit_exact(n, cw, tune):
     """(cw = rows per wave: the launcher's three kernel shapes.)  DC_Filter, LowPassFilter, NotchFilter, FirstOrderDigitalIntegration: 70 channels (more than one wave, ragged
     last wave), three calls in a row so that the carried state (lowpass, notch) and the restart (dc block,
     integrate) are both seen; every row equals the oracle's bit for bit."""
-    tune("SDRX_IIR_CW", cw)
+    tune("SDRX_IIR_CW", abs(cw))
+    tune("SDRX_IIR_PAIR", 1 if cw < 0 else 0)  # cw < 0: the two-wave form with |cw| rows per workgroup
     rng = np.random.default_rng(1000 + n)
     nchan = 70
     epow = device.lowpass1_coef(3000.0, 1.0 / 48000.0)
