@@ -269,14 +269,11 @@ __global__ __launch_bounds__(128) void iir_pair_kernel(const double *x, double *
 }
 
 template <int KIND>
-void launch_iir(int cw, const double *x, double *y, size_t n, size_t nchan, size_t pitch, const IirCoef &k, double *state,
+void launch_iir(int cw, bool pair, const double *x, double *y, size_t n, size_t nchan, size_t pitch, const IirCoef &k, double *state,
                 hipStream_t s)
 {
     dim3 grid((unsigned)((nchan + cw - 1) / cw)), block(64);
-    // two-wave form: where its two waves per row group still find a SIMD each (1024 SIMDs), rows of several chunks.  Measured
-    // (DC blocker / notch, ms): 1024 rows x 2^17 2.61 / 4.61 -> 1.71 / 3.16; 16384 x 2^13 (1024 row groups) 0.46 / 0.46 -> 0.50 / 0.55
-    const int pair = tuning().iir_pair;
-    if (cw != 64 && (pair == 1 || (pair < 0 && grid.x <= 512 && n > 2 * (size_t)IC))) {
+    if (cw != 64 && pair) {
         if (cw == 16) iir_pair_kernel<KIND, 16><<<grid, dim3(128), 0, s>>>(x, y, n, nchan, pitch, k, state);
         else iir_pair_kernel<KIND, 4><<<grid, dim3(128), 0, s>>>(x, y, n, nchan, pitch, k, state);
         return;
@@ -661,18 +658,25 @@ extern "C" int sdrx_iir_dev(int kind, const double *coef, const double *x, doubl
     IirCoef k = {{0, 0, 0, 0, 0}};
     for (int j = 0; j < ncoef[kind]; j++) k.c[j] = coef[j];
     const bool aliased = kind == K_DC && (const double *)y == x; // aliased call: the reference's own in-place behaviour
-    // rows per wave: 16 once that gives every SIMD of the part (1024) a wave, else 4 (64 only on request)
-    int cw = nchan >= 16 * 1024 ? 16 : 4;
+    // rows per wave and one- or two-wave form, by bank size (1024 SIMDs; DC blocker / notch in ms over 2^27 samples,
+    // profiles/r02_iir_pair_probe.txt): from 2049 rows 16 rows per wave -- 4096 rows 0.92 / 1.30 with 4 rows per wave, 0.69 /
+    // 0.88 with 16 and two waves; 8192 rows 0.93 / 1.29 -> 0.45 / 0.51; 12288 rows x 2^13 0.71 / 0.98 -> 0.37 / 0.40 with one
+    // wave -- and the two-wave form while its second wave still finds a SIMD of its own (<= 512 groups of rows:
+    // 1024 rows 2.60 / 4.60 -> 1.71 / 3.14); rows of at most two chunks never (nothing to take in turn)
+    int cw = nchan > 2048 ? 16 : 4;
     if (const int v = tuning().iir_cw; v == 64 || v == 16 || v == 4) cw = v;
+    bool pair = cw != 64 && (nchan + cw - 1) / cw <= 512;
+    if (n <= 2 * (size_t)IC) pair = false;
+    if (const int v = tuning().iir_pair; v == 0 || v == 1) pair = v == 1;
     hipStream_t s = (hipStream_t)stream;
     switch (kind) {
     case K_DC:
-        if (aliased) launch_iir<K_DCA>(cw, x, y, n, nchan, pitch, k, state, s);
-        else launch_iir<K_DC>(cw, x, y, n, nchan, pitch, k, state, s);
+        if (aliased) launch_iir<K_DCA>(cw, pair, x, y, n, nchan, pitch, k, state, s);
+        else launch_iir<K_DC>(cw, pair, x, y, n, nchan, pitch, k, state, s);
         break;
-    case K_LP: launch_iir<K_LP>(cw, x, y, n, nchan, pitch, k, state, s); break;
-    case K_NOTCH: launch_iir<K_NOTCH>(cw, x, y, n, nchan, pitch, k, state, s); break;
-    default: launch_iir<K_INT>(cw, x, y, n, nchan, pitch, k, state, s); break;
+    case K_LP: launch_iir<K_LP>(cw, pair, x, y, n, nchan, pitch, k, state, s); break;
+    case K_NOTCH: launch_iir<K_NOTCH>(cw, pair, x, y, n, nchan, pitch, k, state, s); break;
+    default: launch_iir<K_INT>(cw, pair, x, y, n, nchan, pitch, k, state, s); break;
     }
     SDRX_HIP(hipGetLastError());
     return SDRX_OK;
