@@ -113,6 +113,11 @@ typedef struct sdrx_fir_job {
                                  resident buffer: n_before >= num_taps - 1 (+ decim for sdrx_fir_fmdisc_dev) samples of the
                                  same channel lie in front of in0 and ARE the history (state_in is not read): a stream
                                  tiled in time, every tile its own launch, gives the one-launch results */
+    const void *taps_f32;     /* optional (NULL = absent), sdrx_fir_am_dev with fp64 samples, decim 1, fast_fma 0: device, the
+                                 num_taps taps rounded to float.  With it the chain filters in fp32 and VERIFIES every
+                                 decision against a rigorous error bound; outputs inside the bound are recomputed in the
+                                 reference's fp64 order, so the bits are those of the exact path for every input (a table
+                                 that is not the rounded taps is detected on the device and only costs time) */
 } sdrx_fir_job;
 
 /* Filter::execute (filt.cpp:267-273) on 1 rail (out0) or on I and Q (out0, out1), optionally
@@ -121,6 +126,11 @@ int sdrx_fir_dev(const sdrx_fir_job *job);
 /* Filter::execute on I and Q, then AM<T>::demodulate with downsample = decim (AM.h:63-77):
  * out0 = uint8 0/1 per kept sample. */
 int sdrx_fir_am_dev(const sdrx_fir_job *job);
+/* Debug counters of the verified form of sdrx_fir_am_dev (job.taps_f32), kept per GPU while
+ * sdrx_tune("SDRX_AMV_STATS", "1"): out[0] outputs recomputed in fp64, out[1] waves that recomputed any, out[2] tiles
+ * whose bound was unusable (all outputs recomputed), out[3] unused.  Synchronises the device.  No counterpart in the
+ * reference: there to report the fallback rate next to a measurement. */
+int sdrx_fir_am_verify_stats(uint64_t out[4], int reset);
 /* Filter::execute on I and Q, decimate by D, phase-difference discriminator
  * (rtl_fm.c:422-435, 518-546 in fp64): out0 = double angle (rad) per kept sample. */
 int sdrx_fir_fmdisc_dev(const sdrx_fir_job *job);

@@ -28,7 +28,7 @@ class FirJob(C.Structure):
         ("state_in", _vp), ("state_out", _vp), ("state_pitch", _sz),
         ("out0", _vp), ("out1", _vp), ("out_pitch", _sz), ("n_out", _sz),
         ("stream", _vp), ("dtype", C.c_int), ("u8_flags", C.c_int), ("u8_bias", C.c_double),
-        ("n_before", _sz),
+        ("n_before", _sz), ("taps_f32", _vp),
     ]
 
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "sdrx_fir_dev": (C.c_int, [C.POINTER(FirJob)]),
     "sdrx_fir_am_dev": (C.c_int, [C.POINTER(FirJob)]),
     "sdrx_fir_fmdisc_dev": (C.c_int, [C.POINTER(FirJob)]),
+    "sdrx_fir_am_verify_stats": (C.c_int, [_vp, C.c_int]),
     "sdrx_fir_state_doubles": (_sz, [C.c_int]),
     "sdrx_fir_ring_create": (_vp, [C.POINTER(FirJob), C.c_int, _sz, _sz, _sz, C.c_int]),
     "sdrx_fir_ring_launch": (C.c_int, [_vp, _vp]),

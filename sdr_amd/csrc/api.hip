@@ -59,6 +59,8 @@ Tuning &tuning()
         x.fir_nt = env_int("SDRX_FIR_NT", d.fir_nt);
         x.fir_lds_soft_kb = env_int("SDRX_FIR_LDS_SOFT_KB", d.fir_lds_soft_kb);
         x.fir_ct = env_int("SDRX_FIR_CT", d.fir_ct);
+        x.fir_amv = env_int("SDRX_FIR_AMV", d.fir_amv);
+        x.amv_stats = env_int("SDRX_AMV_STATS", d.amv_stats);
         x.fir_fill = env_int("SDRX_FIR_FILL", d.fir_fill);
         x.psk_split = env_int("SDRX_PSK_SPLIT", d.psk_split);
         x.psk_overlap = env_int("SDRX_PSK_OVERLAP", d.psk_overlap);
@@ -164,6 +166,8 @@ extern "C" int sdrx_tune(const char *name, const char *value)
     else if (strcmp(name, "SDRX_FIR_NT") == 0) t.fir_nt = dflt ? d.fir_nt : v;
     else if (strcmp(name, "SDRX_FIR_LDS_SOFT_KB") == 0) t.fir_lds_soft_kb = dflt ? d.fir_lds_soft_kb : v;
     else if (strcmp(name, "SDRX_FIR_CT") == 0) t.fir_ct = dflt ? d.fir_ct : v;
+    else if (strcmp(name, "SDRX_FIR_AMV") == 0) t.fir_amv = dflt ? d.fir_amv : v;
+    else if (strcmp(name, "SDRX_AMV_STATS") == 0) t.amv_stats = dflt ? d.amv_stats : v;
     else if (strcmp(name, "SDRX_FIR_FILL") == 0) t.fir_fill = dflt ? d.fir_fill : v;
     else if (strcmp(name, "SDRX_PSK_SPLIT") == 0) t.psk_split = dflt ? d.psk_split : v;
     else if (strcmp(name, "SDRX_PSK_OVERLAP") == 0) t.psk_overlap = dflt ? d.psk_overlap : v;
@@ -200,6 +204,9 @@ extern "C" const char *sdrx_last_kernel(void)
             snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s, T=129, D=4 compile-time>", k.a, lay[k.b & 3], epi[k.c % 3]);
         else if (strcmp(k.family, "fir_tile_kernel_ct64x1") == 0)
             snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s, T=64, D=1 compile-time>", k.a, lay[k.b & 3], epi[k.c % 3]);
+        else if (strncmp(k.family, "fir_amv_kernel", 14) == 0)
+            snprintf(one, sizeof(one), "fir_amv_kernel<R=%d, %s, EPI_AM verified, fp32 fma%s>", k.a, lay[k.b & 3],
+                     strcmp(k.family, "fir_amv_kernel_ct64") == 0 ? ", T=64 compile-time" : "");
         else if (strncmp(k.family, "psk_loops", 9) == 0)
             snprintf(one, sizeof(one), "%s<%s>", k.family, k.a == SDRX_BPSK ? "BPSK" : "QPSK");
         else if (strcmp(k.family, "psk_ambiguity_kernel") == 0)
@@ -217,6 +224,16 @@ extern "C" size_t sdrx_fir_state_doubles(int num_taps) { return num_taps > 0 ? (
 extern "C" int sdrx_fir_dev(const sdrx_fir_job *job) { return launch_fir(job, EPI_STORE); }
 extern "C" int sdrx_fir_am_dev(const sdrx_fir_job *job) { return launch_fir(job, EPI_AM); }
 extern "C" int sdrx_fir_fmdisc_dev(const sdrx_fir_job *job) { return launch_fir(job, EPI_DISC); }
+
+extern "C" int sdrx_fir_am_verify_stats(uint64_t out[4], int reset)
+{
+    unsigned long long *d = f32::amv_stats_dev();
+    if (!d) return SDRX_EHIP;
+    SDRX_HIP(hipDeviceSynchronize());
+    if (out) SDRX_HIP(hipMemcpy(out, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) SDRX_HIP(hipMemset(d, 0, 4 * sizeof(uint64_t)));
+    return SDRX_OK;
+}
 
 extern "C" int sdrx_rtlfm_dev(const uint8_t *iq_u8, size_t n, size_t nchan, size_t in_pitch, int downsample, int rotate90,
                               const int32_t *state_in, int32_t *state_out, int16_t *pcm, size_t out_pitch, void *stream)

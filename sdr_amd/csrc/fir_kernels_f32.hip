@@ -7,6 +7,7 @@
 #include "fir_common.h"
 
 #include <array>
+#include <cmath>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -23,6 +24,7 @@ namespace sdrx {
 
 #define FT float
 #define SDRX_FNS f32
+#define SDRX_FIR_AMV 1 /* + the verified fp32 form of the fp64 FIR -> AM chain (cfg1) */
 #include "fir_impl.inc"
 #undef FT
 #undef SDRX_FNS

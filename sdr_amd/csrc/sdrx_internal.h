@@ -40,6 +40,8 @@ struct Tuning {
     int fir_nt = 256;         // SDRX_FIR_NT: lanes per workgroup tile
     int fir_lds_soft_kb = 64; // SDRX_FIR_LDS_SOFT_KB: preferred LDS per workgroup tile
     int fir_fill = 1;         // SDRX_FIR_FILL: 0 = interior tiles stage through the general (bounds-tested) path too
+    int fir_amv = 1;          // SDRX_FIR_AMV: 0 = sdrx_fir_am_dev never takes the verified fp32 kernel (fir_amv_kernel)
+    int amv_stats = 0;        // SDRX_AMV_STATS: 1 = fir_amv_kernel counts its recomputed outputs (sdrx_fir_am_verify_stats)
     int fir_ct = 1;           // SDRX_FIR_CT: 0 = never use the compile-time (T = 129, D = 4) instance of the tile kernel
     int psk_split = -1;       // SDRX_PSK_SPLIT: -1 auto, 0 one-wave loops, 1 two-wave loops
     int fsk_rows = 0;         // SDRX_FSK_ROWS: bits per wave of the FSK correlator (0 auto, 64, 16)
@@ -82,6 +84,12 @@ enum FirEpilogue { EPI_STORE = 0, EPI_AM = 1, EPI_DISC = 2 };
 // kernel on the job's stream -- the launch then allocates nothing even for a geometry not seen before.
 int launch_fir(const sdrx_fir_job *job, FirEpilogue epi, int *offs_buf = nullptr, unsigned offs_cap = 0);
 int launch_fir_mfma(const sdrx_fir_job *job, size_t n_out); // fir_mfma.hip: fast mode 2, fp64 only
+namespace f32 {
+// fir_kernels_f32.hip: dense FIR + AM decision, filtered in fp32 with every decision verified against a rigorous bound and
+// recomputed in the reference's fp64 arithmetic when inside it (bits identical to the exact kernel by construction)
+int launch_fir_amv(const sdrx_fir_job *job, unsigned long long *stats);
+unsigned long long *amv_stats_dev(); // this device's four debug counters (nullptr on failure)
+}
 
 // demod_kernels.hip
 int launch_am_demod(const double *re, const double *im, uint8_t *out, size_t n, size_t ds, hipStream_t s);

@@ -47,6 +47,8 @@ class FirChain:
         self.nchan = int(nchan)
         self.device = torch.device(device)
         self.taps = torch.from_numpy(taps).to(self.device).to(dtype)
+        # the taps rounded to float: with them sdrx_fir_am_dev filters in fp32 and verifies every decision (same bits)
+        self.taps_f32 = torch.from_numpy(taps.astype(np.float32)).to(self.device) if dtype == torch.float64 else None
         self.pitch = int(self.L.sdrx_fir_state_doubles(self.T))
         self.state = [torch.zeros(self.nchan, self.pitch, dtype=dtype, device=self.device) for _ in range(2)]
         self.cur = 0
@@ -77,6 +79,7 @@ class FirChain:
         j.stream = _stream()
         j.dtype = _lib.F32 if self.dtype == torch.float32 else _lib.F64
         j.u8_bias, j.u8_flags = self.u8_bias, self.u8_flags
+        j.taps_f32 = _ptr(self.taps_f32)
         return j
 
     def _run(self, fn, name, layout, in0, in1, n, in_pitch, out0, out1, out_pitch, fast_fma=False, n_out=0):
