@@ -311,8 +311,10 @@ int sdrx_psk_demod_dev(int kind, const double *iq, size_t n, size_t nchan, size_
  * serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same arguments and results as
  * sdrx_psk_demod_dev minus `work`: the matched-filter output and the filter's zero-history rows live in a static
  * device array of SDRX_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds until the process ends.  The
- * call makes no hipMalloc / hipFree (neither does any routine it calls; the array's per-device address is looked up
- * by sdrx_init, or by the first call on a device).  Shapes whose workspace -- sdrx_psk_work_bytes(n, nchan) -- exceeds
+ * call makes no hipMalloc / hipFree (neither does any routine it calls; the array's per-device address and the matched
+ * filter's tap table are looked up by sdrx_init, or by the first call on a device).  A call under HIP stream capture must
+ * therefore be preceded, on that device, by sdrx_init() or by one uncaptured call (symbol lookups do not belong inside a
+ * capture).  Shapes whose workspace -- sdrx_psk_work_bytes(n, nchan) -- exceeds
  * sdrx_psk_demod_noalloc_max_bytes() are rejected with SDRX_EUNSUPPORTED.  Every call on a GPU shares that GPU's
  * array: calls that overlap on one GPU (two streams, two threads) race; serialise them or use sdrx_psk_demod_dev.
  */

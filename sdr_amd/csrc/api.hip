@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <thread>
@@ -61,6 +62,8 @@ Tuning &tuning()
         x.fir_ct = env_int("SDRX_FIR_CT", d.fir_ct);
         x.fir_amv = env_int("SDRX_FIR_AMV", d.fir_amv);
         x.amv_stats = env_int("SDRX_AMV_STATS", d.amv_stats);
+        x.amv_nb = env_int("SDRX_AMV_NB", d.amv_nb);
+        x.amv_dbg = env_int("SDRX_AMV_DBG", d.amv_dbg);
         x.fir_fill = env_int("SDRX_FIR_FILL", d.fir_fill);
         x.psk_split = env_int("SDRX_PSK_SPLIT", d.psk_split);
         x.psk_overlap = env_int("SDRX_PSK_OVERLAP", d.psk_overlap);
@@ -139,7 +142,14 @@ extern "C" int sdrx_init(int device)
     SDRX_HIP(hipFree(nullptr));
     (void)am_threshold_sq();
     (void)tuning();
-    return noalloc_setup(nullptr); // the static scratch's address on this device
+    // Everything a later call would look up on first use, resolved now: a caller that runs sdrx_init() first can make its
+    // first sdrx_psk_demod_noalloc_dev call under stream capture (no symbol lookup inside the capture).  A lookup that
+    // fails here is reported by the entry point that needs it, not by sdrx_init: the rest of the library does not use them.
+    (void)psk_mf_taps_dev();
+    (void)noalloc_setup(nullptr); // the static scratch's address on this device
+    (void)hipGetLastError();
+    g_err[0] = 0;
+    return SDRX_OK;
 }
 
 extern "C" int sdrx_device_count(void)
@@ -168,6 +178,8 @@ extern "C" int sdrx_tune(const char *name, const char *value)
     else if (strcmp(name, "SDRX_FIR_CT") == 0) t.fir_ct = dflt ? d.fir_ct : v;
     else if (strcmp(name, "SDRX_FIR_AMV") == 0) t.fir_amv = dflt ? d.fir_amv : v;
     else if (strcmp(name, "SDRX_AMV_STATS") == 0) t.amv_stats = dflt ? d.amv_stats : v;
+    else if (strcmp(name, "SDRX_AMV_NB") == 0) t.amv_nb = dflt ? d.amv_nb : v;
+    else if (strcmp(name, "SDRX_AMV_DBG") == 0) t.amv_dbg = dflt ? d.amv_dbg : v;
     else if (strcmp(name, "SDRX_FIR_FILL") == 0) t.fir_fill = dflt ? d.fir_fill : v;
     else if (strcmp(name, "SDRX_PSK_SPLIT") == 0) t.psk_split = dflt ? d.psk_split : v;
     else if (strcmp(name, "SDRX_PSK_OVERLAP") == 0) t.psk_overlap = dflt ? d.psk_overlap : v;
@@ -204,9 +216,12 @@ extern "C" const char *sdrx_last_kernel(void)
             snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s, T=129, D=4 compile-time>", k.a, lay[k.b & 3], epi[k.c % 3]);
         else if (strcmp(k.family, "fir_tile_kernel_ct64x1") == 0)
             snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s, T=64, D=1 compile-time>", k.a, lay[k.b & 3], epi[k.c % 3]);
-        else if (strncmp(k.family, "fir_amv_kernel", 14) == 0)
-            snprintf(one, sizeof(one), "fir_amv_kernel<R=%d, %s, EPI_AM verified, fp32 fma%s>", k.a, lay[k.b & 3],
-                     strcmp(k.family, "fir_amv_kernel_ct64") == 0 ? ", T=64 compile-time" : "");
+        else if (strncmp(k.family, "fir_amv_", 8) == 0)
+        {
+            const bool mm = strncmp(k.family, "fir_amv_mfma", 12) == 0;
+            snprintf(one, sizeof(one), "%s<%s=%d, %s, EPI_AM verified, fp32 %s%s>", mm ? "fir_amv_mfma_kernel" : "fir_amv_kernel", mm ? "NB" : "R",
+                     k.a, lay[k.b & 3], mm ? "mfma 16x16x4" : "fma", strstr(k.family, "_ct64") ? ", T=64 compile-time" : "");
+        }
         else if (strncmp(k.family, "psk_loops", 9) == 0)
             snprintf(one, sizeof(one), "%s<%s>", k.family, k.a == SDRX_BPSK ? "BPSK" : "QPSK");
         else if (strcmp(k.family, "psk_ambiguity_kernel") == 0)
@@ -418,26 +433,42 @@ static int mf_launch(const double *iq, size_t n, size_t nchan, size_t in_pitch, 
 // of the library, ordered by events); loop state carries from piece to piece exactly as from call to call.  Same
 // kernels, same arithmetic, same order per channel: results are bit-identical to the one-stream form.
 static const int PSK_PIECES_MAX = 16;
+static const size_t PSK_PIPES_MAX = 64; // caller streams that get a side stream of their own; calls from further ones run on one stream
 struct PskPipe {
     hipStream_t side = nullptr;
     hipEvent_t ev[PSK_PIECES_MAX + 1] = {};
-    bool ready = false;
+    std::mutex mu; // one call's fork / join at a time (two host threads feeding ONE stream is the caller's race, not a crash here)
 };
 static std::mutex g_pipe_mu;
-static std::map<int, PskPipe> g_pipe;
+static std::map<std::pair<int, hipStream_t>, std::unique_ptr<PskPipe>> g_pipe;
 
-static PskPipe *psk_pipe_locked() // g_pipe_mu held; created on the first use on a device, kept until the process ends
+// The side stream and events of (current device, caller's stream): created on the first pipelined call from that stream,
+// kept until the process ends.  EVERY caller stream has its own: a call never queues behind another stream's call, and the
+// only waits the library adds are  side <- event recorded earlier on s  and, at the end,  s <- event recorded earlier on side,
+// all enqueued by one host thread in that order.  (Why that cannot deadlock, and what the round-2 hang was: DESIGN.md
+// section 4, "block pipeline".)  nullptr: no pipe (the caller then runs the one-stream form).
+static PskPipe *psk_pipe_for(hipStream_t s)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    PskPipe &p = g_pipe[dev];
-    if (!p.ready) {
-        bool ok = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) == hipSuccess;
-        for (int k = 0; ok && k <= PSK_PIECES_MAX; k++) ok = hipEventCreateWithFlags(&p.ev[k], hipEventDisableTiming) == hipSuccess;
-        if (!ok) return nullptr;
-        p.ready = true;
+    std::lock_guard<std::mutex> lk(g_pipe_mu);
+    auto key = std::make_pair(dev, s);
+    auto it = g_pipe.find(key);
+    if (it != g_pipe.end()) return it->second.get();
+    if (g_pipe.size() >= PSK_PIPES_MAX) return nullptr;
+    std::unique_ptr<PskPipe> p(new PskPipe);
+    bool ok = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess;
+    int made = 0;
+    for (; ok && made <= PSK_PIECES_MAX; made++) ok = hipEventCreateWithFlags(&p->ev[made], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        for (int k = 0; k < made; k++) (void)hipEventDestroy(p->ev[k]);
+        if (p->side) (void)hipStreamDestroy(p->side);
+        (void)hipGetLastError();
+        return nullptr;
     }
-    return &p;
+    PskPipe *raw = p.get();
+    g_pipe[key] = std::move(p);
+    return raw;
 }
 
 static int psk_demod_common(int kind, const double *iq, size_t n, size_t nchan, size_t in_pitch, sdrx_psk_state *states,
@@ -458,19 +489,18 @@ static int psk_demod_common(int kind, const double *iq, size_t n, size_t nchan, 
     // profiles/r02_cfg3_overlap_trace.json), s_setprio and a high-priority queue notwithstanding: off by default there.
     // Giving each stage CUs of its own (CU-masked queues) is worse still: profiles/r02_cfg3_cumask.json.
     const bool overlap = may_overlap && want != 0 && m >= 512 && (want > 0 || (nchan <= (1u << 13) && m >= 2048));
-    if (!overlap) {
+    // A stream under capture, or one beyond the PSK_PIPES_MAX that have a side stream: the one-stream form (same results).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = overlap && (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone);
+    PskPipe *pp = nullptr;
+    if (!overlap || capturing || !(pp = psk_pipe_for(s))) {
         int rc = mf_launch(iq, n, nchan, in_pitch, mf, m, zst, dst, s, offs_buf, offs_cap);
         if (rc) return rc;
         rc = launch_psk_loops(kind, mf, m, nchan, m, states, out, out_pitch, 1, 1, s);
         if (rc) return rc;
         return launch_psk_ambiguity(kind, out, (m + 1) / 2, nchan, out_pitch, states, s);
     }
-    std::lock_guard<std::mutex> lk(g_pipe_mu); // one call's events at a time
-    PskPipe *pp = psk_pipe_locked();
-    if (!pp) {
-        set_error("sdrx_psk_demod_dev: side streams / events could not be created");
-        return SDRX_EHIP;
-    }
+    std::lock_guard<std::mutex> lk(pp->mu);
     const int pieces = tune.psk_pieces < 2 ? 2 : (tune.psk_pieces > PSK_PIECES_MAX ? PSK_PIECES_MAX : tune.psk_pieces);
     const size_t m_piece = (((m + pieces - 1) / pieces) + 31) & ~(size_t)31; // whole ring blocks (32 samples), even: /2 keeps 0, 2, ...
     hipStream_t s_mf = s, s_lp = pp->side;

@@ -37,3 +37,50 @@ def gather_bits(local_bits, nchan, dst=0):
     if rank != dst:
         return None
     return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def row_checksums(bits):
+    """(rows, n) uint8 -> (rows,) int64 on the CPU: a position-weighted sum per row, so that rows that are swapped,
+    shifted or padded differently do not collide.  The gather's check: every rank sends these over the control
+    backend (gloo), the gathering rank recomputes them from the rows RCCL delivered."""
+    n = bits.shape[1]
+    w = (torch.arange(n, device=bits.device, dtype=torch.int64) % 65521) + 1
+    return (bits.to(torch.int64) * w).sum(dim=1).cpu()
+
+
+def gather_checksums(local_cs, nchan):
+    """Every rank's row checksums in channel order on every rank, as CPU tensors (gloo when the group has it)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_cs
+    world = dist.get_world_size()
+    sizes = [partition(nchan, r, world) for r in range(world)]
+    most = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros(most, dtype=torch.int64)
+    pad[: local_cs.numel()] = local_cs
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)])
+
+
+def pin_to_gpu_numa_node(device_index):
+    """Keep this rank's host threads on the CPUs of its GPU's NUMA node, when sysfs says which that is
+    (/sys/bus/pci/devices/<bdf>/numa_node, /sys/devices/system/node/node<N>/cpulist) and the process may run there.
+    -> the node, or None when nothing was changed (unreadable, node -1, no CPU of the node in the affinity mask)."""
+    import os
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return node
+    except Exception:
+        return None

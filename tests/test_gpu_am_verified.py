@@ -1,0 +1,196 @@
+"""The verified fp32 forms of BASELINE config 1 (fir_amv_kernel: packed fma; fir_amv_mfma_kernel: matrix cores) against
+the oracle's chain -- Filter::execute on I and Q (filt.cpp:248-273) + AM<T>::demodulate (AM.h:63-77) -- on inputs
+ENGINEERED to sit on the decision threshold, on non-finite and extreme samples, with a wrong fp32 tap table, and
+streamed in ragged chunks.  Bar: every bit equal to the oracle's, in every form (SDRX_FIR_AMV = 0 exact fp64 kernel,
+2 packed fma, 3 matrix cores with 2 and 4 blocks per wave, 1 the default choice)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from signals import ook_iq
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from sdr_amd import _lib, device  # noqa: E402
+
+L = O.lib()
+FORMS = [(0, 4), (1, None), (2, 4), (3, 2), (3, 4)]  # (SDRX_FIR_AMV, SDRX_AMV_NB)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    device.init(0)
+    yield
+    torch.cuda.synchronize()
+
+
+def _oracle_bits(taps, re, im, hI=None, hQ=None):
+    T = taps.size
+    hI = np.zeros(max(T - 1, 1)) if hI is None else hI
+    hQ = np.zeros(max(T - 1, 1)) if hQ is None else hQ
+    bits = np.zeros(re.size + 1, dtype=np.uint8)
+    m = L.orc_chain_fir_am(taps, T, hI, hQ, np.ascontiguousarray(re), np.ascontiguousarray(im), re.size, 1, bits)
+    return bits[:m]
+
+
+def _stats(reset=True):
+    a = (C.c_uint64 * 4)()
+    _lib.check(_lib.lib().sdrx_fir_am_verify_stats(a, 1 if reset else 0), "stats")
+    return list(a)
+
+
+def _run_forms(tune, taps, re_rows, im_rows, want_rows, min_recomputed=0, split=False):
+    """re_rows, im_rows: (nchan, n) float64; every form's bits against want_rows."""
+    nchan, n = re_rows.shape
+    re = torch.tensor(re_rows, device="cuda")
+    im = torch.tensor(im_rows, device="cuda")
+    x = (re, im) if split else torch.stack([re, im], dim=-1).contiguous()
+    tune("SDRX_AMV_STATS", 1)
+    for form, nb in FORMS:
+        tune("SDRX_FIR_AMV", form)
+        tune("SDRX_AMV_NB", nb)
+        _stats()
+        ch = device.FirChain(taps, nchan=nchan, decim=1)
+        bits = torch.zeros(nchan, n, dtype=torch.uint8, device="cuda")
+        ch.fir_am(x, bits)
+        torch.cuda.synchronize()
+        got = bits.cpu().numpy()
+        kern = _lib.lib().sdrx_last_kernel().decode()
+        if form == 0:
+            assert "fir_amv" not in kern, kern
+        elif form == 2:
+            assert "fir_amv_kernel" in kern, kern
+        elif form == 3:
+            assert "fir_amv_mfma_kernel" in kern and "NB=%d" % nb in kern, kern
+        bad = np.argwhere(got != want_rows)
+        assert bad.size == 0, (form, nb, kern, bad[:5])
+        st = _stats()
+        if form in (2, 3):
+            assert st[0] >= min_recomputed, (form, nb, st)
+    return st
+
+
+def _steady_bit(taps, c_re, c_im):
+    n = taps.size + 6
+    return int(_oracle_bits(taps, np.full(n, c_re), np.full(n, c_im))[-1])
+
+
+@pytest.mark.parametrize("T,angle", [(64, 0.0), (64, 0.7), (64, np.pi / 4), (33, 2.1), (129, 0.3), (1, 0.0), (17, 1.0)])
+def test_constant_carriers_bisected_onto_the_threshold(T, angle, tune):
+    """A constant carrier a * (cos, sin) settles at |y| = a * |sum h| in the reference's summation order.  Bisect `a` over
+    the doubles until two NEIGHBOURING doubles give different steady-state bits in the oracle, then run the 121 doubles
+    around that point as 121 channels: every steady-state output sits within a few ulp of the threshold, far inside the
+    fp32 bound, so every one of them must take the recomputation and come out with the oracle's bit."""
+    if T == 1:
+        taps = np.array([1.0])
+    else:
+        err, taps = O.fir_design(O.LPF, T, 2.0e6, 1.0e5)
+        assert err == 0
+    cr, ci = np.cos(angle), np.sin(angle)
+    lo, hi = 1.0, 1000.0
+    assert _steady_bit(taps, lo * cr, lo * ci) == 0 and _steady_bit(taps, hi * cr, hi * ci) == 1
+    while np.nextafter(lo, np.inf) < hi:
+        mid = 0.5 * (lo + hi)
+        if _steady_bit(taps, mid * cr, mid * ci):
+            hi = mid
+        else:
+            lo = mid
+    amps = [hi]
+    for _ in range(60):
+        amps.append(np.nextafter(amps[-1], np.inf))
+        amps.insert(0, np.nextafter(amps[0], 0.0))
+    amps = np.array(amps)
+    n = 300
+    re = np.repeat((amps * cr)[:, None], n, axis=1)
+    im = np.repeat((amps * ci)[:, None], n, axis=1)
+    want = np.stack([_oracle_bits(taps, re[c], im[c]) for c in range(amps.size)])
+    steady = want[:, T + 5:]
+    assert steady.min() == 0 and steady.max() == 1  # the 121 channels straddle the threshold
+    _run_forms(tune, taps, re, im, want, min_recomputed=amps.size * (n - T - 5))
+
+
+def test_non_finite_and_extreme_samples(tune):
+    """NaN, +-Inf, huge, tiny and denormal samples dropped into an OOK stream: the outputs they reach fail both certainty
+    tests (or make the tile's bound unusable) and are recomputed in the reference's arithmetic."""
+    err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
+    n = 40000
+    rows_re, rows_im = [], []
+    specials = [np.nan, np.inf, -np.inf, 1e300, -1e300, 1e-300, 5e-324, 1e30, 3.5e38, 7e38, 1e39, -1e39, 2.0 ** 127, 65504.0 * 4]
+    for c, v in enumerate(specials):
+        re, im, _ = ook_iq(n, seed=200 + c, ds=8)
+        rng = np.random.default_rng(300 + c)
+        for p in rng.integers(0, n, 7):
+            (re if p & 1 else im)[p] = v
+        re[n - 3] = v  # inside the carried history too
+        rows_re.append(re)
+        rows_im.append(im)
+    re, im = np.stack(rows_re), np.stack(rows_im)
+    with np.errstate(all="ignore"):
+        want = np.stack([_oracle_bits(taps, re[c], im[c]) for c in range(re.shape[0])])
+    _run_forms(tune, taps, re, im, want)
+    _run_forms(tune, taps, re, im, want, split=True)
+
+
+def test_a_wrong_fp32_tap_table_only_costs_time(tune):
+    """sdrx_fir_job.taps_f32 is the caller's: a table that is not the fp64 taps rounded to float makes every workgroup
+    refuse its bound (stats[2]) and recompute; the bits do not change."""
+    err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
+    n = 30000
+    re, im, _ = ook_iq(n, seed=9, ds=8)
+    want = _oracle_bits(taps, re, im)
+    x = torch.tensor(np.stack([re, im], axis=-1)[None], device="cuda")
+    tune("SDRX_AMV_STATS", 1)
+    for form, nb in FORMS[2:]:
+        tune("SDRX_FIR_AMV", form)
+        tune("SDRX_AMV_NB", nb)
+        for which in ("scaled", "one_tap", "nan"):
+            ch = device.FirChain(taps, nchan=1, decim=1)
+            t32 = ch.taps_f32.clone()
+            if which == "scaled":
+                t32 *= 1.001
+            elif which == "one_tap":
+                t32[40] = torch.nextafter(t32[40], t32[40] * 4)
+                t32[40] = torch.nextafter(t32[40], t32[40] * 4)
+            else:
+                t32[3] = float("nan")
+            ch.taps_f32 = t32
+            _stats()
+            bits = torch.zeros(1, n, dtype=torch.uint8, device="cuda")
+            ch.fir_am(x, bits)
+            torch.cuda.synchronize()
+            st = _stats()
+            assert np.array_equal(bits[0].cpu().numpy(), want), (form, nb, which)
+            assert st[2] > 0 and st[0] == n, (form, nb, which, st)
+
+
+@pytest.mark.parametrize("T", [1, 2, 7, 16, 63, 64, 65, 129, 1000])
+def test_verified_forms_streamed_in_ragged_chunks(T, tune):
+    """State carried over ragged calls (1 sample, fewer than T, not a multiple of anything, more than one tile), and taps
+    whose sum|h| puts the OOK envelope on both sides of the threshold."""
+    if T <= 2:
+        taps = np.array([0.9, -0.4][:T])
+    else:
+        err, taps = O.fir_design(O.LPF, T, 2.0e6, 1.0e5)
+        taps = taps * (1.3 / (np.abs(taps).sum() if T <= 129 else abs(taps.sum())))  # (a long sinc: scaled by its DC gain)
+    n = 150000
+    re, im, _ = ook_iq(n, seed=50 + T, ds=8)
+    cuts = [0, 1, 3, 40, 40 + 2 * T + 1, 9000, 9000 + 8192, 9000 + 8192 + 4097, 77777, n]
+    xd = torch.tensor(np.stack([re, im], axis=-1)[None], device="cuda")
+    hI, hQ = np.zeros(max(T - 1, 1)), np.zeros(max(T - 1, 1))
+    want = np.concatenate([_oracle_bits(taps, re[a:b], im[a:b], hI, hQ) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert 0.02 < want.mean() < 0.98
+    for form, nb in FORMS[1:]:
+        tune("SDRX_FIR_AMV", form)
+        tune("SDRX_AMV_NB", nb)
+        ch = device.FirChain(taps, nchan=1, decim=1)
+        got = torch.zeros(1, n, dtype=torch.uint8, device="cuda")
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ch.fir_am(xd[:, a:b].contiguous(), got[:, a:b])  # (a view of the output row: the pitch is the view's stride)
+        torch.cuda.synchronize()
+        g = got[0].cpu().numpy()
+        assert np.array_equal(g, want), (form, nb, np.flatnonzero(g != want)[:5])

@@ -1605,7 +1605,9 @@ def test_psk_block_pipeline_equals_the_one_stream_form(kind, lk, tune):
             for call in range(2):
                 o = torch.zeros(nchan, b.n_dec, dtype=torch.uint8, device="cuda")
                 if call == 1:
-                    with torch.cuda.stream(torch.cuda.Stream()):
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())  # o's zero fill and call 0's state writes come first
+                    with torch.cuda.stream(side):
                         b.demod(x, o)
                     torch.cuda.synchronize()
                 else:
@@ -1622,6 +1624,55 @@ def test_psk_block_pipeline_equals_the_one_stream_form(kind, lk, tune):
             for call in range(2):
                 want = O.psk_demodulate(st, np.ascontiguousarray(x[c].cpu().numpy().reshape(-1)))
                 assert np.array_equal(res[1][0][call][c][: want.size].astype(np.float64), want), (kind, n, c, call)
+
+
+@pytest.mark.timeout(120)
+def test_psk_block_pipeline_with_many_live_streams(tune):
+    """The block pipeline forks onto a side stream of the library and joins back through events.  Every caller stream has
+    a side stream and events of its own (api.hip psk_pipe_for).  Here: 40 live non-blocking streams (the box gives a
+    process 4 hardware queues, so streams share them), pipelined calls on 8 of them -- back to back on one stream, and
+    interleaved across streams so that pieces of different calls sit in the queues at once -- plus the null stream, then
+    the same on a second round; every result bit-identical to the one-stream form (SDRX_PSK_OVERLAP = 0) and the states too.
+    Run once, under a timeout: a fork / join that could not be satisfied would show as a hang in the final synchronize."""
+    nchan, n = 16, 1 << 15  # the shape that hung in round 2 (16 x 2^15: m = 8192 -> pipelined by default)
+    iqs = [psk_test_signal(O.QPSK, n // 8 + 1, seed=700 + c, phase_deg=41.0 * c, snr_db=18.0, timing_offset=c % 5)[: 2 * n]
+           for c in range(nchan)]
+    x = torch.tensor(np.stack([np.asarray(z).reshape(-1, 2) for z in iqs]), device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(40)]  # all stay alive to the end of the test
+    for s in streams:  # make every one of them a live queue user
+        with torch.cuda.stream(s):
+            torch.zeros(8, device="cuda").add_(1.0)
+    users = [None] + streams[3::5][:8]  # the null stream + 8 of the 40
+    ROUNDS, CALLS = 2, 3
+
+    def run(overlap):
+        tune("SDRX_PSK_OVERLAP", overlap)
+        banks = [device.PskBank(_lib.QPSK, nchan, n) for _ in users]
+        outs = [[torch.zeros(nchan, banks[0].n_dec, dtype=torch.uint8, device="cuda") for _ in range(ROUNDS * CALLS)] for _ in users]
+        torch.cuda.synchronize()
+        for r in range(ROUNDS):
+            for call in range(CALLS):  # interleaved: call `call` of every user before anybody's next call
+                for u, s in enumerate(users):
+                    ctx = torch.cuda.stream(s) if s is not None else torch.cuda.stream(torch.cuda.default_stream())
+                    with ctx:
+                        banks[u].demod(x, outs[u][r * CALLS + call])
+                        if overlap:
+                            assert _lib.lib().sdrx_last_kernel().decode().count("fir_tile_kernel") >= 2  # it was pipelined
+            with torch.cuda.stream(users[1]):  # and back to back on one stream
+                for call in range(CALLS):
+                    banks[1].demod(x, outs[1][r * CALLS + call])
+        torch.cuda.synchronize()
+        return [[o.cpu().numpy() for o in row] for row in outs], [b.states.cpu().numpy() for b in banks]
+
+    o1, s1 = run(-1)  # the default choice: pipelined at this shape
+    o0, s0 = run(0)
+    for u in range(len(users)):
+        assert np.array_equal(s0[u], s1[u]), u
+        for k in range(ROUNDS * CALLS):
+            assert np.array_equal(o0[u][k], o1[u][k]), (u, k)
+    # all users but users[1] ran the same 6 calls from the same initial state
+    for u in range(2, len(users)):
+        assert np.array_equal(s1[u], s1[0]) and all(np.array_equal(a, b) for a, b in zip(o1[u], o1[0]))
 
 
 def test_fir_job_n_before_tiles_a_stream_in_time():
