@@ -53,6 +53,9 @@ def parse_args(argv=None):
                          "go over gloo as CPU tensors, RCCL stays available for GPU tensors (shard.gather_bits) and is not "
                          "initialised unless used; nccl: barrier and scalars as GPU tensors over RCCL; gloo (+ "
                          "SDRX_BENCH_SHARE_GPU=1): rehearse the multi-rank path on a one-GPU box, every rank on cuda:0")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="N = 1 only: form a one-rank process group and run the N > 1 epilogue (shard.gather_bits over RCCL) "
+                         "after the timed region, so that a one-GPU box shows the RCCL path executing")
     ap.add_argument("--shard", action="store_true", help="(kept for older command lines: cfg4 is always sharded)")
     ap.add_argument("--weak", action="store_true",
                     help="cfg4: every rank runs its own 1024 channels x 2^18 instead of a share of 1024 x 2^20")
@@ -373,6 +376,47 @@ def host_threads():
         return os.cpu_count() or 1
 
 
+# ------------------------------------------------------------------------------------------ RCCL epilogue (N > 1)
+
+def gpu_identity(torch, local_rank):
+    """(host, PCI domain, bus, device) of this rank's GPU as 4 int64: ranks that share a GPU cannot form an RCCL communicator."""
+    import zlib
+    pr = torch.cuda.get_device_properties(local_rank)
+    return [zlib.crc32(socket.gethostname().encode()), int(getattr(pr, "pci_domain_id", 0)), int(getattr(pr, "pci_bus_id", -1)),
+            int(getattr(pr, "pci_device_id", -1))]
+
+
+def rccl_gather_epilogue(torch, dist, shard, device, args, rank, world, dev, red_dev, out):
+    """SURVEY 8e / north_star's "RCCL over xGMI only for an optional final gather", OUTSIDE the timed region: every rank
+    demodulates a small block of its own channels (AM threshold on the real rail of 2^14 samples per channel, ds = 8:
+    2048 decision bytes per channel), the rows are collected on rank 0 with shard.gather_bits over RCCL (GPU tensors), and
+    rank 0 checks every gathered row against the checksum its owner sent over the control backend.  Fills `out`."""
+    total = args.channels or 1024
+    lo, hi = shard.partition(total, rank, world)
+    n, ds = 1 << 14, 8
+    x = synth_fm_stream(torch, max(hi - lo, 1) * n, 5000 + lo, dev, restart=n).view(max(hi - lo, 1), n, 2)[: hi - lo]
+    re = x[:, :, 0].contiguous()
+    bits = torch.zeros(hi - lo, n // ds, dtype=torch.uint8, device=dev)
+    if hi > lo:
+        device.am_demod(re, torch.zeros_like(re), bits, ds)
+    torch.cuda.synchronize()
+    cs_all = shard.gather_checksums(shard.row_checksums(bits), total, device=red_dev)
+    times = []
+    full = None
+    for _ in range(3):  # the first call brings the communicator up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        full = shard.gather_bits(bits, total, dst=0, always=True)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    out.update({"rccl_ranks": world, "rccl_init_and_first_gather_ms": times[0], "gather_ms": min(times[1:]),
+                "gather_bytes": total * (n // ds), "gather_rows": total})
+    if rank == 0:
+        ok = full is not None and full.shape[0] == total and bool(torch.equal(shard.row_checksums(full), cs_all))
+        out["gather_verified"] = ok
+        out["gather_ones_fraction"] = float(full.float().mean().item()) if full is not None and full.numel() else None
+
+
 # ------------------------------------------------------------------------------------------ one rank
 
 def worker(args):
@@ -384,12 +428,19 @@ def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.rccl_selftest:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ.get("SDRX_BENCH_SHARE_GPU"):
             local_rank = 0
+        ndev = torch.cuda.device_count()
+        if ndev and local_rank >= ndev:  # a launcher that shows every rank only its own GPU (HIP_VISIBLE_DEVICES per rank)
+            local_rank %= ndev
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -400,6 +451,8 @@ def worker(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     device.init(local_rank)
+    # host threads of a rank next to its GPU (launches, pinned staging): only where several ranks share the host
+    numa_node = shard.pin_to_gpu_numa_node(local_rank) if world > 1 and not os.environ.get("SDRX_BENCH_SHARE_GPU") else None
     red_dev = dev if args.backend == "nccl" else "cpu"
     L = _lib.lib()
 
@@ -413,10 +466,33 @@ def worker(args):
     dt = shard.max_over_ranks(dt, device=red_dev)
 
     total_units = world * w["units"]
+    rccl = {}
     if dist is not None:  # ragged partitions: sum what the ranks really processed
         tu = torch.tensor([float(w["units"])], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tu)
         total_units = int(tu.item())
+        # ---- after the timed region: the optional final gather over RCCL, when every rank has a GPU of its own ----
+        ident = torch.tensor(gpu_identity(torch, local_rank), dtype=torch.int64, device=red_dev)
+        ids = [torch.empty_like(ident) for _ in range(world)]
+        dist.all_gather(ids, ident)
+        distinct = len({tuple(int(v) for v in t.tolist()) for t in ids}) == world
+        if args.backend == "gloo" or not distinct:
+            rccl = {"rccl_ranks": 0, "rccl_skipped": "backend gloo" if args.backend == "gloo" else "ranks share a GPU"}
+        else:
+            import threading
+
+            def run():
+                try:
+                    torch.cuda.set_device(local_rank)
+                    rccl_gather_epilogue(torch, dist, shard, device, args, rank, world, dev, red_dev, rccl)
+                except Exception as ex:  # the epilogue must never cost the headline line
+                    rccl.update({"rccl_ranks": 0, "rccl_error": repr(ex)[:300]})
+
+            th = threading.Thread(target=run, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("SDRX_BENCH_RCCL_TIMEOUT_S", "120")))
+            if th.is_alive():  # a communicator that never comes up: report it, print the line, leave without the final barrier
+                rccl = {"rccl_ranks": 0, "rccl_error": "timeout"}
     if rank == 0:
         launch_s = ev_ms / 1e3 / args.steps  # HIP events on the launch stream, averaged over the timed steps
         res = {
@@ -430,6 +506,10 @@ def worker(args):
             "config": w["cfg"],
             "roofline": roofline_of(wl, w, launch_s, kernel),
         }
+        if dist is not None:
+            res.update({k: v for k, v in rccl.items() if k in ("rccl_ranks", "gather_ms")})
+            res["rccl"] = dict(rccl, numa_node=numa_node, what="epilogue after the timed region: shard.gather_bits over RCCL, "
+                               "rows verified on rank 0 against checksums sent over the control backend; the timed region has no collective")
         plain = args.dtype == "f64" and args.ingest == "fp"
         taps, D = w["taps"], w["D"]
         del w
@@ -444,8 +524,14 @@ def worker(args):
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(taps, D, threads, 25 if threads <= 16 else 23)
         print(json.dumps(res), flush=True)
     if dist is not None:
-        barrier()
-        dist.destroy_process_group()
+        if rccl.get("rccl_error") == "timeout":
+            sys.stdout.flush()
+            os._exit(0)  # (a thread is still inside RCCL: tearing the group down would wait for it)
+        try:
+            barrier()
+            dist.destroy_process_group()
+        except Exception as ex:  # a peer that left after an RCCL timeout: the line is out already
+            print(f"bench.py: rank {rank}: {ex!r} at the final barrier", file=sys.stderr)
 
 
 def extra_configs(torch, args, dev, L):

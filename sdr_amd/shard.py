@@ -22,10 +22,11 @@ def max_over_ranks(seconds, device="cpu"):
     return float(t.item())
 
 
-def gather_bits(local_bits, nchan, dst=0):
+def gather_bits(local_bits, nchan, dst=0, always=False):
     """Optional epilogue: collect every rank's (channels_owned, n_bits) uint8 decisions on `dst` in
-    channel order.  Ragged partitions are padded to the largest shard for the collective."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    channel order.  Ragged partitions are padded to the largest shard for the collective.
+    always: go through the collective even in a group of one rank (bench.py --rccl-selftest)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return local_bits
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [partition(nchan, r, world) for r in range(world)]
@@ -48,18 +49,19 @@ def row_checksums(bits):
     return (bits.to(torch.int64) * w).sum(dim=1).cpu()
 
 
-def gather_checksums(local_cs, nchan):
-    """Every rank's row checksums in channel order on every rank, as CPU tensors (gloo when the group has it)."""
+def gather_checksums(local_cs, nchan, device="cpu"):
+    """Every rank's row checksums in channel order on every rank (returned on the CPU).  device = where the collective's
+    tensors live: "cpu" = the control backend (gloo) when the group has one, a cuda device for an RCCL-only group."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local_cs
     world = dist.get_world_size()
     sizes = [partition(nchan, r, world) for r in range(world)]
     most = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros(most, dtype=torch.int64)
-    pad[: local_cs.numel()] = local_cs
+    pad = torch.zeros(most, dtype=torch.int64, device=device)
+    pad[: local_cs.numel()] = local_cs.to(device)
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
-    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)])
+    return torch.cat([bufs[r][: hi - lo].cpu() for r, (lo, hi) in enumerate(sizes)])
 
 
 def pin_to_gpu_numa_node(device_index):

@@ -57,3 +57,19 @@ def test_bench_default_backend_keeps_the_control_traffic_on_gloo():
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     r = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
     assert r["n_gpus"] == 2 and r["config"]["channels_per_gpu"] == 4
+    assert r["rccl_ranks"] == 0 and r["rccl"]["rccl_skipped"] == "ranks share a GPU"  # detected, not attempted
+
+
+def test_bench_rccl_epilogue_on_one_rank():
+    """The N > 1 epilogue -- shard.gather_bits over RCCL, rows verified against checksums -- through a one-rank group:
+    what a one-GPU box can show of it (the library loads, a communicator comes up, the collective runs on GPU tensors)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "SDRX_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "cfg4", "--steps", "2",
+                        "--warmup", "1", "--no-cpu", "--no-extra", "--log2n", "12", "--channels", "65", "--rccl-selftest"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    r = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert r["rccl_ranks"] == 1 and r["rccl"]["gather_verified"] is True, r["rccl"]
+    assert r["rccl"]["gather_rows"] == 65 and r["gather_ms"] > 0 and 0.0 < r["rccl"]["gather_ones_fraction"] < 1.0
