@@ -65,7 +65,10 @@ def parse_args(argv=None):
                                                             "stays 2^26 samples); cfg4: total channels (default 1024)")
     ap.add_argument("--bpsk", action="store_true", help="cfg3: BPSK instead of QPSK")
     ap.add_argument("--fast-fma", action="store_true")
-    ap.add_argument("--mfma", action="store_true", help="cfg5: fp64 MFMA Toeplitz formulation (fast mode 2)")
+    ap.add_argument("--mfma", action="store_true", help="cfg5: fp64 MFMA Toeplitz formulation (fast mode 2): cfg5's default")
+    ap.add_argument("--exact", action="store_true",
+                    help="cfg5: the VALU convolution with the CPU's two roundings per tap (bit-identical samples) instead of the "
+                         "MFMA formulation (fused chain, within north_star's 1e-12 on filtered samples)")
     return ap.parse_args(argv)
 
 
@@ -154,6 +157,45 @@ def synth_ook_stream(torch, n, seed, dev, amp=100.0, spb=8, noise=10.0, phase=0.
     return out
 
 
+def synth_psk_bank(torch, bank, kind, nchan, n, seed, dev, snr_db=20.0, uw_every=256):
+    """SURVEY 8d's cfg3 input, made on the device with the library's own modulator (sdrx_psk_modulate_dev = the
+    reference's encode_LUT + encode_pulseShape, 8 samples per symbol): random symbols framed with the demodulator's unique
+    word every `uw_every` symbols (placed reversed, the way the ambiguity pass compares: BPSK.cpp:456, QPSK.cpp:428), carrier
+    phase 0 / 90 / 180 / 270 degrees by channel, a timing offset of channel % 5 samples, white Gaussian noise at `snr_db`.
+    The whole bank is modulated as one symbol stream and cut into channels.  -> (nchan, n, 2) interleaved complex fp64."""
+    import ctypes as C
+    import math
+
+    from sdr_amd import _lib
+    L = _lib.lib()
+    nsym = n // 8
+    g = torch.Generator(device=dev).manual_seed(seed)
+    bpsk = kind == _lib.BPSK
+    sym = torch.randint(0, 2 if bpsk else 4, (nchan, nsym), generator=g, device=dev, dtype=torch.uint8)
+    st0 = _lib.PskState.from_buffer_copy(bank.states[0].cpu().numpy().tobytes())
+    # the state keeps a BPSK word in uw[0][0 .. size) and a QPSK word in the LAST `size` of its 64 entries (QPSK.cpp:96-110)
+    uw = [int(st0.uw[0][j if bpsk else 64 - st0.uw_size + j]) for j in range(st0.uw_size)]
+    pat = torch.tensor(uw[::-1], dtype=torch.uint8, device=dev)
+    for at in range(96, nsym - len(uw), uw_every):
+        sym[:, at:at + len(uw)] = pat
+    re = torch.empty(nchan * n, dtype=torch.float64, device=dev)
+    im = re if bpsk else torch.empty_like(re)  # BPSK: both rails carry the same data (TEST_Modulator_Demodulator.cpp:41-46)
+    _lib.check(L.sdrx_psk_modulate_dev(kind, C.c_void_p(sym.data_ptr()), nchan * nsym, C.c_void_p(re.data_ptr()),
+                                       None if bpsk else C.c_void_p(im.data_ptr()), nchan * n,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "sdrx_psk_modulate_dev")
+    re, im = re.view(nchan, n), im.view(nchan, n)
+    x = torch.empty(nchan, n, 2, dtype=torch.float64, device=dev)
+    sigma = math.sqrt(float((re * re + im * im).mean().item()) / (10.0 ** (snr_db / 10.0)) / 2.0)
+    for q, (c, s_) in enumerate(((1.0, 0.0), (0.0, 1.0), (-1.0, 0.0), (0.0, -1.0))):  # z * e^{j 90 q}
+        x[q::4, :, 0] = re[q::4] * c - im[q::4] * s_
+        x[q::4, :, 1] = im[q::4] * c + re[q::4] * s_
+    for k in range(1, 5):
+        x[k::5] = torch.roll(x[k::5], k, dims=1)
+    for lo in range(0, nchan, 1024):
+        x[lo:lo + 1024] += torch.randn(x[lo:lo + 1024].shape, generator=g, device=dev, dtype=torch.float64) * sigma
+    return x
+
+
 def lpf_taps(T, Fs, Fx, max_taps=1 << 20):
     import numpy as np
     from sdr_amd import _lib
@@ -179,7 +221,7 @@ def build_workload(wl, args, rank, world, dev):
     def as_input(x):  # synthetic samples are integers in [-127, 127]: byte = x + 127
         return (x + 127.0).to(torch.uint8).contiguous() if u8 else x.to(tdt)
 
-    w = {"scaling": "weak", "flop_per_sample": None, "taps": None, "D": None}
+    w = {"scaling": "weak", "flop_per_sample": None, "taps": None, "D": None, "report": None}
     if wl in ("cfg2", "cfg4"):
         D, T, Fs = args.decim, args.taps, 2.4e6
         taps = lpf_taps(T, Fs, 1.0e5)
@@ -225,7 +267,7 @@ def build_workload(wl, args, rank, world, dev):
         x = torch.randint(-127, 128, (nchan, n), generator=g, device=dev).to(torch.float64)
         chain = device.FirChain(taps, nchan=nchan, decim=1, device=dev)
         out = torch.zeros(nchan, n, dtype=torch.float64, device=dev)
-        mode = 2 if args.mfma else (1 if args.fast_fma else 0)
+        mode = 0 if args.exact else (1 if args.fast_fma else 2)  # cfg5 hands back filtered SAMPLES: the 1e-12 tolerance is north_star's own
         w.update(step=lambda: chain.fir(x, out, fast_fma=mode), units=nchan * n, bytes_per_sample=16.0,
                  flop_per_sample=2.0 * T,
                  cfg={"workload": "cfg5: 1024-tap Filter(LPF) bank, one real rail per channel, "
@@ -236,11 +278,18 @@ def build_workload(wl, args, rank, world, dev):
     else:  # cfg3
         lc = (args.channels or (1 << 14)).bit_length() - 1
         nchan, n = 1 << lc, 1 << ((args.log2n or 26) - lc)
-        g = torch.Generator(device=dev).manual_seed(7 + rank)
-        x = torch.randn(nchan, n, 2, generator=g, device=dev, dtype=torch.float64) * 0.3
         kind = _lib.BPSK if args.bpsk else _lib.QPSK
         bank = device.PskBank(kind, nchan, n, device=dev)
+        x = synth_psk_bank(torch, bank, kind, nchan, n, 7 + rank, dev)
         out = torch.zeros(nchan, bank.n_dec, dtype=torch.uint8, device=dev)
+        hits_at = _lib.PskState.n_hits.offset
+
+        def report():  # the unique-word hits the last step's ambiguity pass found: the fold ran on real frames
+            h = bank.states[:, hits_at:hits_at + 4].contiguous().view(torch.int32).view(-1)
+            return {"uw_hits_last_step": int(h.sum().item()), "channels_with_uw_hits": int((h > 0).sum().item()),
+                    "input": "framed symbols (unique word every 256), product modulator, phase 0/90/180/270 by channel, "
+                             "timing offset channel % 5, AWGN 20 dB"}
+        w["report"] = report
         w.update(step=lambda: bank.demod(x, out), units=nchan * n, bytes_per_sample=16.125,
                  flop_per_sample=129.0 * 2 * 2 / 4,  # matched filter only: 129 taps x 2 rails x (mul + add), every 4th output
                  cfg={"workload": ("cfg3: BPSK" if args.bpsk else "cfg3: QPSK")
@@ -510,12 +559,14 @@ def worker(args):
             res.update({k: v for k, v in rccl.items() if k in ("rccl_ranks", "gather_ms")})
             res["rccl"] = dict(rccl, numa_node=numa_node, what="epilogue after the timed region: shard.gather_bits over RCCL, "
                                "rows verified on rank 0 against checksums sent over the control backend; the timed region has no collective")
+        if w["report"]:
+            res["config"] = dict(res["config"], **w["report"]())
         plain = args.dtype == "f64" and args.ingest == "fp"
         taps, D = w["taps"], w["D"]
         del w
         torch.cuda.empty_cache()
         if world == 1 and not args.no_extra and wl == "cfg2" and plain:
-            res["extra"] = {"configs": extra_configs(torch, args, dev, L),
+            res["extra"] = {"configs": extra_configs(torch, args, dev, L), "host_layer": host_layer(torch, dev, L),
                             "note": "short runs (20 warm-up + 50 timed steps) of the other BASELINE configs in this process, "
                                     "after the headline; frac_hbm = algorithmic bytes / launch time / 8 TB/s"}
         if world == 1 and not args.no_cpu and wl == "cfg2" and plain:
@@ -541,7 +592,7 @@ def extra_configs(torch, args, dev, L):
     # cfg3's 2^26 samples: as 2^14 channels x 2^12 (enough channels to put a wave pair on half of the SIMDs) and as the
     # 1024 channels x 2^16 of SURVEY 8d (16 wave pairs walking 16384 serial loop steps each: latency-bound by design)
     runs = [("cfg1", []), ("cfg3", []), ("cfg3_bpsk", ["--bpsk"]), ("cfg3_1024ch", ["--channels", "1024"]), ("cfg4", []),
-            ("cfg5", []), ("cfg5_mfma", ["--mfma"])]
+            ("cfg5", []), ("cfg5_exact", ["--exact"])]
     for name, flags in runs:
         a = parse_args(["--workload", name.split("_")[0], "--steps", "50", "--warmup", "20"] + flags)
         try:
@@ -555,6 +606,8 @@ def extra_configs(torch, args, dev, L):
                  "Msamples_per_s": w["units"] * a.steps / dt / 1e6, "launch_ms": launch_s * 1e3, "kernel": kernel,
                  "frac_hbm": w["bytes_per_sample"] * w["units"] / launch_s / 1e9 / HBM_PEAK_GBS,
                  "algorithmic_bytes_per_sample": w["bytes_per_sample"]}
+            if w["report"]:
+                e.update(w["report"]())
             comp = roof.get("compute") or (roof if roof["bound"] == "mfma" else None)
             if comp:
                 e["compute"] = {k: comp[k] for k in ("achieved", "peak", "unit", "frac") if k in comp}
@@ -565,6 +618,104 @@ def extra_configs(torch, args, dev, L):
         except Exception as ex:  # an extra must never cost the headline line
             out[name] = {"error": repr(ex)}
         torch.cuda.empty_cache()
+    return out
+
+
+def host_layer(torch, dev, L):
+    """The drop-in boundary as its callers meet it (rtlsdr_receiver.cpp:1974-2116, ProfileTest/main.cpp:129-191): HOST
+    buffers in, host buffers out, every call synchronous; PCIe-inclusive, so never the headline `value`.  Each entry:
+    Msamples/s, ms per call, host bytes moved per second, and the share of the measured pinned-copy rate that is."""
+    import numpy as np
+
+    from sdr_amd import device, host
+    out = {}
+    rng = np.random.default_rng(11)
+
+    def timed(fn, min_s=0.6, max_calls=50):
+        fn()  # warm-up: staging buffers, streams
+        k, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            k += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_s or k >= max_calls:
+                return dt / k
+
+    # the PCIe ceiling on this box: pinned host <-> device copies of 256 MiB
+    pin = torch.empty(1 << 28, dtype=torch.uint8).pin_memory()
+    d = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+
+    def h2d():
+        d.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+
+    def d2h():
+        pin.copy_(d, non_blocking=True)
+        torch.cuda.synchronize()
+    h2d_gbs, d2h_gbs = (1 << 28) / timed(h2d, 0.3) / 1e9, (1 << 28) / timed(d2h, 0.3) / 1e9
+    del pin, d
+    out["pcie"] = {"h2d_pinned_GBps": h2d_gbs, "d2h_pinned_GBps": d2h_gbs,
+                   "note": "torch pinned <-> device copies of 256 MiB on this box: the ceiling of every entry below"}
+
+    def entry(name, what, n_samples, bytes_in, bytes_out, sec):
+        floor = bytes_in / (h2d_gbs * 1e9) + bytes_out / (d2h_gbs * 1e9)  # both directions at the measured copy rates, back to back
+        out[name] = {"what": what, "samples_per_call": n_samples, "ms_per_call": sec * 1e3, "Msamples_per_s": n_samples / sec / 1e6,
+                     "host_GBps": (bytes_in + bytes_out) / sec / 1e9, "bytes_in": bytes_in, "bytes_out": bytes_out,
+                     "pcie_floor_ms": floor * 1e3, "frac_of_pcie_floor": floor / sec}
+
+    try:
+        n = 1 << 25
+        taps = lpf_taps(64, 2.4e6, 1.0e5)
+        re = rng.integers(-127, 128, n).astype(np.float64)
+        im = rng.integers(-127, 128, n).astype(np.float64)
+        ch = host.Chain(taps, 10)
+        entry("chain_fir_fmdisc_f64", "host.Chain.fir_fmdisc = sdrx_chain_fir_fmdisc: cfg2 chain on two fp64 host rails of 2^25 samples",
+              n, 16 * n, 8 * (n // 10), timed(lambda: ch.fir_fmdisc(re, im)))
+        raw = rng.integers(0, 256, (n, 2)).astype(np.uint8)
+        entry("chain_fir_fmdisc_u8", "sdrx_chain_fir_fmdisc_u8: the same chain from the radio's raw uint8 {I,Q} bytes (converted on the device)",
+              n, 2 * n, 8 * (n // 10), timed(lambda: ch.fir_fmdisc_u8(raw)))
+        f = host.Filter(host.LPF, 64, 2.4e6, 1.0e5)
+        buf = re.copy()
+        entry("filter_execute", "host.Filter.execute = Filter::execute (filt.cpp:267-273), in place on 2^25 doubles",
+              n, 8 * n, 8 * n, timed(lambda: f.execute(buf)))
+        del ch, raw, f, buf
+        nf = 64
+        filters = [host.Filter(host.LPF, 64, 2.4e6, 1.0e5) for _ in range(nf)]
+        bufs = [re.copy() for _ in range(nf)]  # 16 GiB of host doubles
+        entry("fir_execute_batch_64", "sdrx_fir_execute_batch: 64 Filter objects x 2^25 doubles each, in place, one call",
+              nf * n, 8 * n * nf, 8 * n * nf, timed(lambda: host.fir_execute_batch(filters, bufs), 0.1, 2))
+        del filters, bufs
+        # the single-radio sizes BASELINE names
+        n1 = 1 << 20
+        taps1 = lpf_taps(64, 2.0e6, 1.0e5)
+        c1 = host.Chain(taps1, 1)
+        r1, i1 = re[:n1].copy(), im[:n1].copy()
+        entry("cfg1_one_2^20_buffer", "host.Chain.fir_am: BASELINE configs[0] as stated, ONE 2^20-sample I/Q buffer per call (host in, host bits out)",
+              n1, 16 * n1, n1, timed(lambda: c1.fir_am(r1, i1), 0.3, 200))
+        del c1
+    except Exception as ex:
+        out["error"] = repr(ex)[:300]
+    try:  # cfg2 as the receiver streams it: 2^18-sample chunks, state carried, 8 chunk launches replayed from one HIP graph
+        chunks, nchunk = 8, 1 << 18
+        taps = lpf_taps(64, 2.4e6, 1.0e5)
+        x = synth_fm_stream(torch, chunks * nchunk, 77, dev).view(chunks, nchunk, 2)
+        chain = device.FirChain(taps, nchan=1, decim=10, device=dev)
+        o = torch.zeros(chunks, chain.n_out(nchunk), dtype=torch.float64, device=dev)
+        ring = device.FirRing(chain, x, o, epilogue="fmdisc", use_graph=2)
+
+        def replay():
+            ring.launch()
+            torch.cuda.synchronize()
+        sec = timed(replay, 0.3, 500)
+        out["cfg2_ring_of_2^18_chunks"] = {"what": "sdrx_fir_ring_*: cfg2 in 2^18-sample chunks (device-resident ring of 8, state carried, one HIP "
+                                                   "graph replay + synchronize per 8 chunks)", "samples_per_call": chunks * nchunk,
+                                           "ms_per_call": sec * 1e3, "us_per_chunk": sec / chunks * 1e6,
+                                           "Msamples_per_s": chunks * nchunk / sec / 1e6,
+                                           "frac_hbm": 16.8 * chunks * nchunk / sec / 1e9 / HBM_PEAK_GBS}
+        del ring, chain, x, o
+    except Exception as ex:
+        out["cfg2_ring_error"] = repr(ex)[:300]
+    torch.cuda.empty_cache()
     return out
 
 

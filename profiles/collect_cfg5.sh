@@ -5,7 +5,7 @@ set -u
 TAG=${1:-r01}
 export TMPDIR=/tmp
 for v in exact fma mfma; do
-  case $v in exact) FL="";; fma) FL="--fast-fma";; mfma) FL="--mfma";; esac
+  case $v in exact) FL="--exact";; fma) FL="--fast-fma";; mfma) FL="--mfma";; esac
   OUT=gpurun_out/prof/${TAG}_cfg5_$v
   mkdir -p $OUT
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o cfg5 --output-format csv -- python3 bench.py --workload cfg5 --steps 20 --warmup 5 --no-cpu $FL > $OUT/kt.log 2>&1 || exit 1

@@ -1184,6 +1184,7 @@ def test_config3_full_shape_bank():
     nchan, n, distinct = 1 << 14, 1 << 12, 64
     bank = device.PskBank(_lib.QPSK, nchan, n)
     sts = [O.psk_new(O.QPSK, math_mode=O.MATH_SHARED) for _ in range(distinct)]
+    sts_libm = [O.psk_new(O.QPSK, math_mode=O.MATH_LIBM) for _ in range(distinct)]  # the CPU path's own cos / sin
     for blk in range(2):
         sig = np.stack([psk_test_signal(O.QPSK, n // 8, seed=7000 + 100 * blk + c, phase_deg=(29 * c) % 360, snr_db=16.0,
                                         timing_offset=c % 8).reshape(n, 2) for c in range(distinct)])
@@ -1200,14 +1201,17 @@ def test_config3_full_shape_bank():
             want = O.psk_demodulate(sts[c], np.ascontiguousarray(sig[c].reshape(-1)))
             assert np.array_equal(got[c][: want.size].astype(np.float64), want), (blk, c)
             assert np.array_equal(hs[c][: 8 * 24].view(np.float64), sts[c].loop_state()), (blk, c)
+            # north_star's bit-exact bitstream is against the CPU path, i.e. libm's cos / sin in the carrier loop
+            want_libm = O.psk_demodulate(sts_libm[c], np.ascontiguousarray(sig[c].reshape(-1)))
+            assert np.array_equal(got[c][: want_libm.size].astype(np.float64), want_libm), (blk, c, "libm")
 
 
 def test_config4_full_shape_bank():
-    """BASELINE config 4 at full shape (1024 channels x 2^18 samples of the config-2 chain in one launch): 16 distinct
+    """BASELINE config 4 at the shape bench.py times (1024 channels x 2^20 samples of the config-2 chain in one launch): 16 distinct
     streams repeated 64 times: every copy equals the first; the 16 distinct rows equal the same streams run one channel
     at a time (a different grid, the same bits) and the oracle on their first 3000 outputs; carried state included."""
     err, taps = O.fir_design(O.LPF, 64, 2.4e6, 1.0e5)
-    nchan, n, D, distinct = 1024, 1 << 18, 10, 16
+    nchan, n, D, distinct = 1024, 1 << 20, 10, 16  # 16 GiB of input, 0.8 GiB of output
     g = torch.Generator(device="cuda").manual_seed(99)
     base = torch.randint(-127, 128, (distinct, n, 2), generator=g, device="cuda").to(torch.float64)
     iq = base.repeat(nchan // distinct, 1, 1).contiguous()
@@ -1417,6 +1421,7 @@ def test_config3_full_shape_bank_bpsk():
     nchan, n, distinct, uw = 1 << 14, 1 << 12, 64, 0xDEADBEEF600DF00D
     bank = device.PskBank(_lib.BPSK, nchan, n, unique_word=uw, uw_len=64)
     sts = [O.psk_new(O.BPSK, uw, 64, O.MATH_SHARED) for _ in range(distinct)]
+    sts_libm = [O.psk_new(O.BPSK, uw, 64, O.MATH_LIBM) for _ in range(distinct)]
     for blk in range(2):
         sig = np.stack([psk_test_signal(O.BPSK, n // 8, seed=8000 + 100 * blk + c, phase_deg=(31 * c) % 360, snr_db=16.0,
                                         timing_offset=c % 8, uw_bpsk=uw).reshape(n, 2) for c in range(distinct)])
@@ -1434,6 +1439,45 @@ def test_config3_full_shape_bank_bpsk():
             assert np.array_equal(got[c][: want.size].astype(np.float64), want), (blk, c)
             assert np.array_equal(hs[c][: 8 * 24].view(np.float64), sts[c].loop_state()), (blk, c)
             assert int(hs[c][8 * 24: 8 * 24 + 4].view(np.int32)[0]) == sts[c].cc[0]
+            want_libm = O.psk_demodulate(sts_libm[c], np.ascontiguousarray(sig[c].reshape(-1)))
+            assert np.array_equal(got[c][: want_libm.size].astype(np.float64), want_libm), (blk, c, "libm")
+            assert sts_libm[c].cc[0] == sts[c].cc[0]
+
+
+@pytest.mark.parametrize("kind,lk", [(O.QPSK, _lib.QPSK), (O.BPSK, _lib.BPSK)])
+def test_config3_in_surveys_split_1024_channels_x_2_16(kind, lk):
+    """BASELINE config 3 in SURVEY 8d's own split -- 1024 channels x 2^16 samples, the shape bench.py's cfg3_1024ch line
+    times and the one that takes the BLOCK PIPELINE by default (m = 2^14 >= 2048, nchan <= 2^13): 16 distinct framed
+    signals repeated 64 times.  Every copy equals the first (decisions and states); the 16 distinct channels equal the
+    oracle's full chain: decisions with shared math AND with libm, all 24 loop-state doubles, the confidence counters."""
+    nchan, n, distinct = 1024, 1 << 16, 16
+    bank = device.PskBank(lk, nchan, n)
+    sts = [O.psk_new(kind, math_mode=O.MATH_SHARED) for _ in range(distinct)]
+    sts_libm = [O.psk_new(kind, math_mode=O.MATH_LIBM) for _ in range(distinct)]
+    sig = np.stack([psk_test_signal(kind, n // 8, seed=9100 + c, phase_deg=90.0 * (c % 4) + (0.0 if c < 8 else 7.0), snr_db=20.0,
+                                    timing_offset=c % 8).reshape(n, 2) for c in range(distinct)])
+    iq = torch.tensor(sig, device="cuda").repeat(nchan // distinct, 1, 1).contiguous()
+    out = torch.zeros(nchan, bank.n_dec, dtype=torch.uint8, device="cuda")
+    bank.demod(iq, out)
+    chain = _lib.lib().sdrx_last_kernel().decode()
+    assert chain.count("fir_tile_kernel") >= 2, chain  # cut in time into pieces: the pipelined path
+    torch.cuda.synchronize()
+    o = out.view(nchan // distinct, distinct, -1)
+    assert torch.equal(o, o[0:1].expand_as(o))
+    stt = bank.states.view(nchan // distinct, distinct, -1)
+    assert torch.equal(stt, stt[0:1].expand_as(stt))
+    got, hs = out[:distinct].cpu().numpy(), bank.states[:distinct].cpu().numpy()
+    hits = 0
+    for c in range(distinct):
+        want = O.psk_demodulate(sts[c], np.ascontiguousarray(sig[c].reshape(-1)))
+        assert np.array_equal(got[c][: want.size].astype(np.float64), want), c
+        assert np.array_equal(hs[c][: 8 * 24].view(np.float64), sts[c].loop_state()), c
+        ncc = 1 if kind == O.BPSK else 4
+        assert list(hs[c][8 * 24: 8 * 24 + 4 * ncc].view(np.int32)) == list(sts[c].cc[:ncc]), c
+        want_libm = O.psk_demodulate(sts_libm[c], np.ascontiguousarray(sig[c].reshape(-1)))
+        assert np.array_equal(got[c][: want_libm.size].astype(np.float64), want_libm), (c, "libm")
+        hits += int(hs[c][8 * 24 + 20: 8 * 24 + 24].view(np.int32)[0])
+    assert hits > 0  # the unique word was found: the ambiguity fold ran on real hits
 
 
 def test_config1_at_its_stated_size():
