@@ -735,9 +735,18 @@ static double phase_loop_filter(orc_psk *s, double val)
     return r;
 }
 
+/* include/sdrx_math.h's two sincos forms over an array (tests: distance from libm).  form 0 = sdrx_sincos, 1 = sdrx_sincos_tab */
+void orc_sincos(const double *x, size_t n, int form, double *sn, double *cs)
+{
+    for (size_t i = 0; i < n; i++) {
+        if (form == 1) sdrx_sincos_tab(x[i], SDRX_SINCOS_TAB, &sn[i], &cs[i]);
+        else sdrx_sincos(x[i], &sn[i], &cs[i]);
+    }
+}
+
 static void dds(orc_psk *s, double arg, double *c, double *sn)
 {
-    if (s->math_mode == ORC_MATH_SHARED) sdrx_sincos(arg, sn, c);
+    if (s->math_mode == ORC_MATH_SHARED) sdrx_sincos_tab(arg, SDRX_SINCOS_TAB, sn, c); /* the carrier loop's form (psk_kernels.hip) */
     else {
         *c = cos(arg);
         *sn = sin(arg);

@@ -201,4 +201,7 @@ double orc_normalize(double *block, size_t n, double prev_max);                 
 size_t orc_fifth_order_decimate(double *data, size_t n, size_t decimate_by, double *state6); /* fifth_order_filter.cpp:65-88; state = r_a..r_f */
 void orc_fft(double *iq, size_t n, int math_mode);                               /* FFT.cpp:7-28, n a power of two, interleaved complex */
 
+/* include/sdrx_math.h's sincos forms over an array: form 0 = sdrx_sincos, 1 = sdrx_sincos_tab (the PSK carrier loop's) */
+void orc_sincos(const double *x, size_t n, int form, double *sn, double *cs);
+
 #endif

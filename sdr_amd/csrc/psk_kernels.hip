@@ -65,6 +65,14 @@ const double RRC_COEFF[129] = {SDRX_RRC_VALUES};
 
 // ------------------------------------------------------------------------------------- loops
 
+static __device__ const double d_sincos_tab[128] = {SDRX_SINCOS_TAB_VALUES};
+
+// the workgroup's copy of sdrx_sincos_tab's table (1 KB); the caller puts a barrier behind it
+__device__ __forceinline__ void sincos_table_to_lds(double *tab)
+{
+    for (unsigned i = threadIdx.x; i < 128; i += blockDim.x) tab[i] = d_sincos_tab[i];
+}
+
 struct Interp {
     double d1, d2, d3, d4, d5;
 };
@@ -130,14 +138,15 @@ __device__ __forceinline__ void timing_step(TimingState &t, double &re, double &
 // One sample through phase_shift_correction + the output lookup; returns the decision.
 // SPECULATE: only sincos's straight-line common case runs and `rare` collects its "argument out of range" flag: the
 // caller repeats the block without SPECULATE if any lane raised it (sdrx_math.h: sdrx_sincos_core).
+// cos / sin: sdrx_sincos_tab (include/sdrx_math.h), its 64-entry table in LDS (`tab`: sincos_table_to_lds).
 template <int KIND, bool SPECULATE = false>
-__device__ __forceinline__ int phase_step(PhaseState &p, double re, double im, bool *rare = nullptr)
+__device__ __forceinline__ int phase_step(PhaseState &p, double re, double im, const double *tab, bool *rare = nullptr)
 {
     const double PK1 = 0.0620001240002480, PK2 = 0.000992001984003968; // BPSK.cpp:424-432
     double sn, cs;
     auto sincos_of = [&](double a) {
-        if constexpr (SPECULATE) *rare |= sdrx_sincos_core(a, &sn, &cs) != 0;
-        else sdrx_sincos(a, &sn, &cs);
+        if constexpr (SPECULATE) *rare |= sdrx_sincos_tab_core(a, tab, &sn, &cs) != 0;
+        else sdrx_sincos_tab(a, tab, &sn, &cs);
     };
     if constexpr (KIND == SDRX_BPSK) { // BPSK.cpp:399-411
         sincos_of(p.dds_delay + p.temp);
@@ -181,6 +190,11 @@ __global__ void __launch_bounds__(64) psk_loops_kernel(double2 *__restrict__ mf,
                                                        sdrx_psk_state *__restrict__ states, uint8_t *__restrict__ dec,
                                                        size_t out_pitch, double *__restrict__ carry, int piece)
 {
+    __shared__ __align__(16) double tab[128];
+    if constexpr (PHASE) {
+        sincos_table_to_lds(tab);
+        __syncthreads();
+    }
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchan) return;
     // latency-bound chains: when a throughput kernel (the next piece's matched filter) shares the SIMD, issue first
@@ -198,7 +212,7 @@ __global__ void __launch_bounds__(64) psk_loops_kernel(double2 *__restrict__ mf,
     // what the carrier loop (or the store, in a timing-only run) does with the timing loop's sample i
     auto finish = [&](double re, double im, size_t i, bool even) {
         if constexpr (PHASE) {
-            const int decision = phase_step<KIND>(p, re, im);
+            const int decision = phase_step<KIND>(p, re, im, tab);
             if (even) d[i >> 1] = (uint8_t)decision; // decimate(real, n, 2): keeps 0, 2, 4, ...
         } else {
             x[i] = make_double2(re, im);
@@ -269,6 +283,8 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
                                                               double *__restrict__ carry, int piece)
 {
     __shared__ double2 ring[2][SPLIT_KB][64];
+    __shared__ __align__(16) double tab[128];
+    sincos_table_to_lds(tab); // (the first barrier of the block loop below comes before the carrier wave's first step)
     __builtin_amdgcn_s_setprio(3); // latency-bound chains: issue ahead of a throughput kernel sharing the SIMD
     const unsigned lane = threadIdx.x & 63;
     const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -303,7 +319,7 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
         for (int k = 0; k < SPLIT_KB; k++) {
             const double2 v = ring[jb & 1][k][lane];
             if (decltype(full)::value || i0 + k < m) {
-                const int decision = phase_step<KIND, decltype(speculate)::value>(p, v.x, v.y, &rare);
+                const int decision = phase_step<KIND, decltype(speculate)::value>(p, v.x, v.y, tab, &rare);
                 if ((k & 1) == 0 && active) d[(i0 + k) >> 1] = (uint8_t)decision; // SPLIT_KB is even: parity of k
             }
         }
@@ -360,6 +376,201 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
     }
 }
 
+// The same on THREE waves (three SIMDs of a CU).  A lone wave pays about 8 cycles per dependent fp64 instruction and 5 per
+// independent one (profiles/probes/issue_probe.hip), so a loop's step time is its instruction count: the timing wave's 62
+// against the carrier wave's 48 (table sincos).  16 of the 62 -- InterpolationFilter's V1 ... V6 and its delay-line
+// rotation on both rails (BPSK.cpp:323-328,336-341) -- depend on the input samples only, not on mu: wave 0 runs them one
+// ring block ahead and hands (V3, V6, d5) per rail through a second LDS ring; wave 1 finishes the interpolator
+// (V7 = V3*mu + V6; V8 = d5 + mu*V7) and runs the rest of the timing loop; wave 2 is the carrier loop.  The same
+// operations in the same order on the same values: the same bits.  The delay lines live in wave 0 (it stores them back),
+// everything else of the timing state in wave 1.
+constexpr int TRI_KB = 16; // samples per ring block: ring A 96 KB + ring B 32 KB (one workgroup per CU)
+
+struct InterpPrefix { double V3, V6, d5; };
+__device__ __forceinline__ InterpPrefix interp_prefix(Interp &d, double in)
+{
+    const double K = -0.5; // BPSK.cpp:319-344, the statements that do not read mu
+    const double Kin = K * in;
+    const double V1 = d.d1 - Kin;
+    const double V2 = V1 + d.d2;
+    const double V3 = V2 - d.d3;
+    const double V4 = Kin - d.d1 + d.d4;
+    const double V5 = V4 + d.d2;
+    const double V6 = d.d3 + V5;
+    const InterpPrefix r = {V3, V6, d.d5};
+    d.d3 = d.d2;
+    d.d2 = d.d1;
+    d.d1 = Kin;
+    d.d5 = d.d4;
+    d.d4 = in;
+    return r;
+}
+
+// timing_step with the interpolator's prefix already done (q, i: rails "Q" and "I" of this sample)
+__device__ __forceinline__ void timing_step_tail(TimingState &t, const InterpPrefix &q, const InterpPrefix &i, double &re, double &im)
+{
+    const double strobe = (t.nco < 0) ? 1.0 : 0.0;
+    t.reg_mu = (strobe >= 1) ? t.mu_delay * 2 : t.reg_mu;
+    const double mu = t.reg_mu;
+    const double V7q = q.V3 * mu + q.V6, Q = q.d5 + mu * V7q;
+    const double V7i = i.V3 * mu + i.V6, I = i.d5 + mu * V7i;
+    const double eg = (t.g3 * (-SDRX_SGN(Q) + SDRX_SGN(t.g4)) + (t.g1 * (-SDRX_SGN(I) + SDRX_SGN(t.g2))));
+    const double e = (strobe >= 0.5) ? eg : 0.0;
+    t.g2 = t.g1;
+    t.g1 = I;
+    t.g4 = t.g3;
+    t.g3 = Q;
+    const double K1 = -0.00587880145347487, K2 = -2.35152058138995e-05;
+    const double v = t.lf_y + K2 * e + K1 * (e - t.lf_x);
+    t.lf_x = e;
+    t.lf_y = v;
+    const double eta = t.nco - floor(t.nco);
+    t.nco = eta - 0.5 - v;
+    t.mu_delay = eta;
+    t.reg_Q = (strobe >= 1) ? Q : t.reg_Q;
+    t.reg_I = (strobe >= 1) ? I : t.reg_I;
+    re = t.reg_Q;
+    im = t.reg_I;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(192) psk_loops_tri_kernel(const double2 *__restrict__ mf, size_t m, size_t nchan,
+                                                            size_t pitch, sdrx_psk_state *__restrict__ states,
+                                                            uint8_t *__restrict__ dec, size_t out_pitch,
+                                                            double *__restrict__ carry, int piece)
+{
+    extern __shared__ __align__(16) unsigned char tri_smem[];
+    typedef double2 (*ring_a_t)[TRI_KB][3][64]; // [buffer][sample][(V3q,V6q) | (V3i,V6i) | (d5q,d5i)][lane]
+    typedef double2 (*ring_b_t)[TRI_KB][64];    // [buffer][sample][lane]: (reg_Q, reg_I)
+    ring_a_t ringA = (ring_a_t)tri_smem;
+    ring_b_t ringB = (ring_b_t)(tri_smem + sizeof(double2) * 2 * TRI_KB * 3 * 64);
+    double *tab = (double *)(tri_smem + sizeof(double2) * 2 * TRI_KB * 4 * 64);
+    sincos_table_to_lds(tab); // (two barriers of the block loop come before the carrier wave's first step)
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t c0 = (size_t)blockIdx.x * 64 + lane;
+    const bool active = c0 < nchan;
+    const size_t c = active ? c0 : nchan - 1; // idle lanes shadow the last channel and store nothing
+    sdrx_psk_state *st = states + c;
+    const double2 *x = mf + c * pitch;
+    uint8_t *d = dec + c * out_pitch;
+    const size_t nblocks = (m + TRI_KB - 1) / TRI_KB;
+
+    Interp iq = {st->iq_d[0], st->iq_d[1], st->iq_d[2], st->iq_d[3], st->iq_d[4]};
+    Interp ii = {st->ii_d[0], st->ii_d[1], st->ii_d[2], st->ii_d[3], st->ii_d[4]};
+    TimingState t = {st->nco_delay, st->reg_mu, st->reg_Q, st->reg_I, st->mu_delay, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0},
+                     st->g1, st->g2, st->g3, st->g4, st->lf_x, st->lf_y};
+    PhaseState p = {st->dds_delay, st->plf_x, st->plf_y, 0.0, 0.0, 0.0};
+    if (piece & PIECE_NOT_FIRST) { p.tr = carry[4 * c]; p.ti = carry[4 * c + 1]; p.temp = carry[4 * c + 2]; }
+
+    auto prefix_block = [&](auto full, const double2 (&cur)[TRI_KB], size_t j) {
+#pragma unroll
+        for (int k = 0; k < TRI_KB; k++) {
+            if (decltype(full)::value || j * TRI_KB + k < m) { // uniform: m is the same for all lanes
+                const InterpPrefix q = interp_prefix(iq, cur[k].x); // "Q" is fed the real rail (BPSK.cpp:311)
+                const InterpPrefix i = interp_prefix(ii, cur[k].y);
+                ringA[j & 1][k][0][lane] = make_double2(q.V3, q.V6);
+                ringA[j & 1][k][1][lane] = make_double2(i.V3, i.V6);
+                ringA[j & 1][k][2][lane] = make_double2(q.d5, i.d5);
+            }
+        }
+    };
+    // The ring reads of step k + TRI_PF are issued before step k's arithmetic (and before its ring write, which the
+    // compiler must assume to alias them): an LDS round trip is longer than a quarter of a step, and a lone wave has
+    // nothing else to run while it waits.  (Reading a whole ring block, stale entries past the call's end included, is
+    // harmless: their values are never used.)
+    constexpr int TRI_PF = 3;
+    auto timing_block = [&](auto full, size_t j) {
+        double2 a[TRI_KB], b[TRI_KB], dd[TRI_KB];
+#pragma unroll
+        for (int k = 0; k < TRI_PF; k++) { a[k] = ringA[j & 1][k][0][lane]; b[k] = ringA[j & 1][k][1][lane]; dd[k] = ringA[j & 1][k][2][lane]; }
+#pragma unroll
+        for (int k = 0; k < TRI_KB; k++) {
+            if (k + TRI_PF < TRI_KB) {
+                a[k + TRI_PF] = ringA[j & 1][k + TRI_PF][0][lane];
+                b[k + TRI_PF] = ringA[j & 1][k + TRI_PF][1][lane];
+                dd[k + TRI_PF] = ringA[j & 1][k + TRI_PF][2][lane];
+            }
+            if (decltype(full)::value || j * TRI_KB + k < m) {
+                const InterpPrefix q = {a[k].x, a[k].y, dd[k].x}, i = {b[k].x, b[k].y, dd[k].y};
+                double re, im;
+                timing_step_tail(t, q, i, re, im);
+                ringB[j & 1][k][lane] = make_double2(re, im);
+            }
+        }
+    };
+    auto carrier_block = [&](auto full, auto speculate, size_t jb, bool &rare) {
+        const size_t i0 = jb * TRI_KB;
+        double2 v[TRI_KB];
+#pragma unroll
+        for (int k = 0; k < TRI_KB; k++) v[k] = ringB[jb & 1][k][lane]; // (nothing is written to LDS by this wave: all up front)
+#pragma unroll
+        for (int k = 0; k < TRI_KB; k++) {
+            if (decltype(full)::value || i0 + k < m) {
+                const int decision = phase_step<KIND, decltype(speculate)::value>(p, v[k].x, v[k].y, tab, &rare);
+                if ((k & 1) == 0 && active) d[(i0 + k) >> 1] = (uint8_t)decision; // TRI_KB is even: parity of k
+            }
+        }
+    };
+    typedef std::integral_constant<bool, true> yes_t;
+    typedef std::integral_constant<bool, false> no_t;
+    double2 nxt[TRI_KB];
+    if (role == 0) {
+#pragma unroll
+        for (int k = 0; k < TRI_KB; k++) nxt[k] = ((size_t)k < m) ? x[k] : make_double2(0.0, 0.0);
+    }
+    // iteration j: wave 0 on block j, wave 1 on block j-1, wave 2 on block j-2; one barrier per iteration.  A ring buffer
+    // written in iteration j is read in iteration j+1 and written again in j+2: two buffers each.
+    for (size_t j = 0; j < nblocks + 2; j++) {
+        if (role == 0) {
+            if (j < nblocks) {
+                double2 cur[TRI_KB];
+#pragma unroll
+                for (int k = 0; k < TRI_KB; k++) cur[k] = nxt[k];
+                const size_t nb = (j + 1) * TRI_KB; // the next block's samples land during this block's arithmetic
+                if (nb + TRI_KB <= m) {
+#pragma unroll
+                    for (int k = 0; k < TRI_KB; k++) nxt[k] = x[nb + k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < TRI_KB; k++) nxt[k] = (nb + k < m) ? x[nb + k] : make_double2(0.0, 0.0);
+                }
+                if (nb <= m) prefix_block(yes_t(), cur, j);
+                else prefix_block(no_t(), cur, j);
+            }
+        } else if (role == 1) {
+            if (j >= 1 && j - 1 < nblocks) {
+                if (j * TRI_KB <= m) timing_block(yes_t(), j - 1);
+                else timing_block(no_t(), j - 1);
+            }
+        } else if (j >= 2) {
+            const PhaseState p0 = p; // (speculation on sincos's common case: see psk_loops_split_kernel)
+            bool rare = false;
+            if ((j - 1) * TRI_KB <= m) carrier_block(yes_t(), yes_t(), j - 2, rare);
+            else carrier_block(no_t(), yes_t(), j - 2, rare);
+            if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+                p = p0;
+                carrier_block(no_t(), no_t(), j - 2, rare);
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    if (role == 0) {
+        st->iq_d[0] = iq.d1; st->iq_d[1] = iq.d2; st->iq_d[2] = iq.d3; st->iq_d[3] = iq.d4; st->iq_d[4] = iq.d5;
+        st->ii_d[0] = ii.d1; st->ii_d[1] = ii.d2; st->ii_d[2] = ii.d3; st->ii_d[3] = ii.d4; st->ii_d[4] = ii.d5;
+    } else if (role == 1) {
+        st->nco_delay = t.nco; st->reg_mu = t.reg_mu; st->reg_Q = t.reg_Q; st->reg_I = t.reg_I; st->mu_delay = t.mu_delay;
+        st->g1 = t.g1; st->g2 = t.g2; st->g3 = t.g3; st->g4 = t.g4;
+        st->lf_x = t.lf_x; st->lf_y = t.lf_y;
+    } else {
+        st->dds_delay = p.dds_delay; st->plf_x = p.plf_x; st->plf_y = p.plf_y;
+        if (piece & PIECE_NOT_LAST) { carry[4 * c] = p.tr; carry[4 * c + 1] = p.ti; carry[4 * c + 2] = p.temp; }
+    }
+}
+constexpr size_t TRI_LDS_BYTES = sizeof(double2) * 2 * TRI_KB * 4 * 64 + 128 * sizeof(double);
+
 int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch, sdrx_psk_state *states,
                      uint8_t *decisions, size_t out_pitch, int run_timing, int run_phase, hipStream_t s, double *carry,
                      int piece)
@@ -380,6 +591,18 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
     // (the two-wave form holds 64 KB of LDS per workgroup: two per CU, 512 at a time; measured, loops alone, two-wave /
     // one-wave: 2^15 channels 0.125 / 0.181 ms, 2^16 0.128 / 0.119, 2^17 0.146 / 0.115)
     const bool split = split_env >= 0 ? split_env != 0 : blocks <= 512;
+    // the three-wave form (132 KB of LDS: one workgroup per CU) while every workgroup has a CU to itself
+    const bool tri = split_env >= 0 ? split_env == 2 : blocks <= 256;
+    if (run_timing && run_phase && tri) {
+        typedef void (*tri_fn)(const double2 *, size_t, size_t, size_t, sdrx_psk_state *, uint8_t *, size_t, double *, int);
+        tri_fn fn = kind == SDRX_BPSK ? (tri_fn)psk_loops_tri_kernel<SDRX_BPSK> : (tri_fn)psk_loops_tri_kernel<SDRX_QPSK>;
+        SDRX_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS_BYTES));
+        hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(192), TRI_LDS_BYTES, s, (const double2 *)mf_iq, m, nchan, mf_pitch, states,
+                           decisions, out_pitch, carry, piece);
+        SDRX_HIP(hipGetLastError());
+        note_kernel("psk_loops_tri_kernel", kind, 0, 0, 0);
+        return SDRX_OK;
+    }
     if (run_timing && run_phase && split) {
         if (kind == SDRX_BPSK)
             hipLaunchKernelGGL(psk_loops_split_kernel<SDRX_BPSK>, dim3((unsigned)blocks), dim3(128), 0, s,

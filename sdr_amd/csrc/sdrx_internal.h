@@ -45,7 +45,7 @@ struct Tuning {
     int amv_dbg = 0;          // SDRX_AMV_DBG: timing experiments (wrong results)
     int amv_stats = 0;        // SDRX_AMV_STATS: 1 = fir_amv_kernel counts its recomputed outputs (sdrx_fir_am_verify_stats)
     int fir_ct = 1;           // SDRX_FIR_CT: 0 = never use the compile-time (T = 129, D = 4) instance of the tile kernel
-    int psk_split = -1;       // SDRX_PSK_SPLIT: -1 auto, 0 one-wave loops, 1 two-wave loops
+    int psk_split = -1;       // SDRX_PSK_SPLIT: -1 auto, 0 one-wave loops, 1 two-wave loops, 2 three-wave loops
     int fsk_rows = 0;         // SDRX_FSK_ROWS: bits per wave of the FSK correlator (0 auto, 64, 16)
     int psk_pieces = 4;       // SDRX_PSK_PIECES: pieces a call is cut into by the block pipeline (2..16)
     int psk_overlap = -1;     // SDRX_PSK_OVERLAP: -1 auto, 0 one stream, 1 block pipeline on two streams

@@ -127,6 +127,8 @@ def lib():
     L.orc_rtlfm_full.restype = _sz
     L.orc_rtlfm_low_pass_real.argtypes = [_i16, C.c_int, C.c_int, C.c_int, _i32]
     L.orc_rtlfm_low_pass_real.restype = C.c_int
+    L.orc_sincos.argtypes = [_f64, _sz, C.c_int, _f64, _f64]
+    L.orc_sincos.restype = None
     L.orc_decimate.argtypes = [_f64, _sz, _sz]
     L.orc_decimate.restype = _sz
     L.orc_upsample_fill_w_zeros.argtypes = [_f64, _sz, _f64, _sz, C.c_double]

@@ -1235,17 +1235,18 @@ def test_config4_full_shape_bank():
 
 
 def test_psk_loops_one_wave_and_two_wave_forms_agree(tune):
-    """psk_loops_kernel (both loops interleaved in one wave) and psk_loops_split_kernel (timing and carrier
-    loop on two waves through an LDS ring) are picked by channel count; forced either way they give the
-    same decisions and state, and both match the oracle (odd lengths, 3 blocks, 70 channels)."""
+    """psk_loops_kernel (both loops interleaved in one wave), psk_loops_split_kernel (timing and carrier loop on two
+    waves through an LDS ring) and psk_loops_tri_kernel (the interpolator's mu-independent prefix on a third wave, a
+    second ring) are picked by channel count; forced each way they give the same decisions and state, and all match
+    the oracle (odd lengths incl. ones that end inside a ring block of either kernel, 3 blocks, 70 channels)."""
     nchan = 70
-    for n in (4096, 4096 - 8 * 5):
+    for n in (4096, 4096 - 8 * 5, 4 * (16 * 7 + 2), 4 * 14, 4 * 34):
         iqs = [psk_test_signal(O.BPSK if c % 2 else O.QPSK, n // 8, seed=300 + c, phase_deg=45.0 * c, snr_db=15.0,
                                timing_offset=c % 4) for c in range(nchan)]
         for kind, lk in ((O.QPSK, _lib.QPSK), (O.BPSK, _lib.BPSK)):
             x = torch.tensor(np.stack([np.asarray(z).reshape(-1, 2) for z in iqs]), device="cuda")
             res = {}
-            for force in ("0", "1"):
+            for force in ("0", "1", "2"):
                 tune("SDRX_PSK_SPLIT", force)
                 b = device.PskBank(lk, nchan, n)
                 outs = []
@@ -1253,10 +1254,12 @@ def test_psk_loops_one_wave_and_two_wave_forms_agree(tune):
                     o = torch.zeros(nchan, b.n_dec, dtype=torch.uint8, device="cuda")
                     b.demod(x, o)
                     outs.append(o.cpu().numpy())
+                assert ("psk_loops_kernel", "psk_loops_split_kernel", "psk_loops_tri_kernel")[int(force)] in _lib.lib().sdrx_last_kernel().decode()
                 res[force] = (outs, b.states.cpu().numpy())
-            for a, bb in zip(res["0"][0], res["1"][0]):
-                assert np.array_equal(a, bb), (kind, n)
-            assert np.array_equal(res["0"][1], res["1"][1]), (kind, n)
+            for other in ("1", "2"):
+                for a, bb in zip(res["0"][0], res[other][0]):
+                    assert np.array_equal(a, bb), (kind, n, other)
+                assert np.array_equal(res["0"][1], res[other][1]), (kind, n, other)
             st = O.psk_new(kind, math_mode=O.MATH_SHARED)
             for blk in range(3):
                 want = O.psk_demodulate(st, iqs[0])
