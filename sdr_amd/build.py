@@ -19,6 +19,11 @@ SOURCES = ["api.hip", "fir_kernels.hip", "fir_kernels_fma.hip", "fir_kernels_f32
 HEADERS = [os.path.join(CSRC, h) for h in ("sdrx_internal.h", "fir_common.h", "fir_impl.inc")] + [
     os.path.join(HERE, "..", "include", "sdrx.h"), os.path.join(HERE, "..", "include", "sdrx_math.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wno-comment"]
+# Per-source additions (none in use).  Tried for psk_kernels.hip: -mllvm -amdgpu-sched-strategy=max-ilp -- the PSK loops run
+# ONE wave per SIMD, which pays 8.4 cycles for an instruction that waits for the one before it and 5.2 for an independent one
+# (profiles/probes/issue_probe.hip) -- but the strategy leaves the loop blocks' order as it was (39 % of their vector
+# instructions still follow their producer directly) and the loops' time unchanged (2.742 against 2.749 ms, 1024 x 2^16).
+EXTRA_FLAGS = {}
 
 
 def _newer(path, deps):
@@ -40,8 +45,8 @@ def build(force=False, verbose=True):
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")
-        if force or _newer(obj, [src] + HEADERS):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+        if force or _newer(obj, [src, os.path.abspath(__file__)] + HEADERS):
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
