@@ -251,8 +251,13 @@ int sdrx_fifth_order_decimate_dev(double *data, size_t n, size_t nchan, size_t p
 int sdrx_fifth_order_decimate_block_dev(double *iq, size_t n_points, size_t nchan, size_t pitch, size_t decimate_by,
                                         double *state12, size_t *n_points_out, void *stream);
 /* fft (FFT.cpp:7-28): in-place radix-2 transforms of nchan rows of n complex doubles (pitch in complex elements),
- * n a power of two <= SDRX_FFT_MAX; twiddles from sdrx_math.h's sincos (<= 1e-12 of the libm build). */
+ * n any power of two up to 2^SDRX_FFT_MAX_LOG2_ANY, like the reference's recursion; twiddles from sdrx_math.h's sincos
+ * (<= 1e-12 of the libm build).  Up to SDRX_FFT_MAX points a transform runs in LDS (one launch for all rows); longer
+ * ones as permutation + 4096-point blocks in LDS + the upper stages from global memory (launches per row).
+ * The first call for a length <= SDRX_FFT_MAX on a device allocates that length's twiddle table: sdrx_init() makes all
+ * of them, so a call under stream capture needs sdrx_init() (or one uncaptured call) before it. */
 #define SDRX_FFT_MAX 4096
+#define SDRX_FFT_MAX_LOG2_ANY 28
 int sdrx_fft_dev(double *iq, size_t n, size_t nchan, size_t pitch, void *stream);
 
 /* AM<T>::modulate (AM.h:41-54) = raw_upsample (Resample.h:15-27) over nchan bit streams (one byte per bit): every bit

@@ -735,6 +735,13 @@ static double phase_loop_filter(orc_psk *s, double val)
     return r;
 }
 
+/* libm's cos and sin as TWO calls, the way the reference's -O0 build makes them (RadioNode/CMakeLists.txt:8).  At -O2 gcc
+ * merges a cos / sin pair of one argument into a single sincos() call, and glibc's sincos() differs from its own cos() /
+ * sin() in the last bit for a few arguments per thousand (seen: 2 of 4096 twiddles of a 4096-point fft): calling through
+ * volatile pointers keeps the calls apart. */
+static double (*volatile libm_cos)(double) = cos;
+static double (*volatile libm_sin)(double) = sin;
+
 /* include/sdrx_math.h's two sincos forms over an array (tests: distance from libm).  form 0 = sdrx_sincos, 1 = sdrx_sincos_tab */
 void orc_sincos(const double *x, size_t n, int form, double *sn, double *cs)
 {
@@ -748,8 +755,8 @@ static void dds(orc_psk *s, double arg, double *c, double *sn)
 {
     if (s->math_mode == ORC_MATH_SHARED) sdrx_sincos_tab(arg, SDRX_SINCOS_TAB, sn, c); /* the carrier loop's form (psk_kernels.hip) */
     else {
-        *c = cos(arg);
-        *sn = sin(arg);
+        *c = libm_cos(arg);
+        *sn = libm_sin(arg);
     }
 }
 
@@ -1150,7 +1157,7 @@ static void fft_rec(double *x, size_t N, int math_mode)
     for (size_t k = 0; k < h; k++) {
         double theta = -2 * 3.141592653589793238460 * (double)k / (double)N, wr, wi;
         if (math_mode == ORC_MATH_SHARED) sdrx_sincos(theta, &wi, &wr);
-        else wr = cos(theta), wi = sin(theta);
+        else wr = libm_cos(theta), wi = libm_sin(theta);
         wr = 1.0 * wr, wi = 1.0 * wi;
         double tr = wr * odd[2 * k] - wi * odd[2 * k + 1], ti = wr * odd[2 * k + 1] + wi * odd[2 * k];
         x[2 * k] = even[2 * k] + tr, x[2 * k + 1] = even[2 * k + 1] + ti;

@@ -146,6 +146,7 @@ extern "C" int sdrx_init(int device)
     // first sdrx_psk_demod_noalloc_dev call under stream capture (no symbol lookup inside the capture).  A lookup that
     // fails here is reported by the entry point that needs it, not by sdrx_init: the rest of the library does not use them.
     (void)psk_mf_taps_dev();
+    (void)fft_warm_tables(); // (sdrx_fft_dev under capture: its tables exist)
     (void)noalloc_setup(nullptr); // the static scratch's address on this device
     (void)hipGetLastError();
     g_err[0] = 0;

@@ -509,7 +509,9 @@ __device__ __forceinline__ void fft_group(v2d *x, const v2d *tw, unsigned st, un
 // before the current one's stages run, so that the load latency is not a phase of its own.  L2 != 0: log2 N known at
 // compile time (every stride, shift and folded constant becomes an immediate); L2 == 0: any length.  Whole-transform
 // tiles stream their rows with nontemporal accesses (measured: 2-4 % faster there, 7 % slower on tiles of short rows).
-template <int NT, bool ONE, int L2>
+// NOREV: the rows are already in bit-reversed order (one block of a longer transform whose global permutation has been
+// done: sdrx_fft_dev above SDRX_FFT_MAX points).
+template <int NT, bool ONE, int L2, bool NOREV = false>
 __global__ __launch_bounds__(NT) void fft_kernel(double *iq, const v2d *__restrict__ tw_g, unsigned log2n_, unsigned log2b_,
                                                  size_t pitch, unsigned nchan)
 {
@@ -538,6 +540,7 @@ __global__ __launch_bounds__(NT) void fft_kernel(double *iq, const v2d *__restri
     const unsigned own_fwd = fft_pad(threadIdx.x), own_rev = fft_pad(__brev(threadIdx.x) >> (32 - log2n));
     auto slot_rev = [&](unsigned q) { // where element q goes: bit-reversed inside its transform
         const unsigned hi = NT * q;
+        if constexpr (NOREV) return fft_pad(threadIdx.x + hi);
         if (split) return own_rev ^ fft_pad((hi & ~(N - 1)) + (__brev(hi & (N - 1)) >> (32 - log2n)));
         const unsigned i = threadIdx.x + hi;
         return fft_pad((i & ~(N - 1)) + (__brev(i & (N - 1)) >> (32 - log2n)));
@@ -574,11 +577,18 @@ __global__ __launch_bounds__(NT) void fft_kernel(double *iq, const v2d *__restri
 
 constexpr int FFT_MAX_LOG2 = 12;
 static_assert((1 << FFT_MAX_LOG2) == SDRX_FFT_MAX, "table size");
-v2d *g_fft_tw[64][FFT_MAX_LOG2 + 1];
+struct FftTable {
+    v2d *p = nullptr;
+    hipEvent_t filled = nullptr; // recorded behind the kernel that fills the table
+    bool done = false;           // that event has been seen complete: nothing to wait for any more
+};
+FftTable g_fft_tw[64][FFT_MAX_LOG2 + 1];
 bool g_fft_attr[64];
 std::mutex g_fft_mu;
 
-// twiddle table of one length on the current device; the first call for a length allocates and fills it
+// Twiddle table of one length on the current device.  The first call for a length allocates it and fills it on `s`
+// (hipMalloc: not possible while `s` is being captured -- sdrx_init() makes all twelve tables, 64 KB, so that a caller
+// that ran it never gets here); calls on other streams wait for the fill through an event, never through a stream sync.
 int fft_twiddles(unsigned log2n, hipStream_t s, const v2d **out)
 {
     int dev = 0;
@@ -595,21 +605,98 @@ int fft_twiddles(unsigned log2n, hipStream_t s, const v2d **out)
                               (const void *)fft_kernel<256, true, 10>,  (const void *)fft_kernel<256, true, 11>,
                               (const void *)fft_kernel<1024, true, 12>, (const void *)fft_kernel<1024, false, 6>,
                               (const void *)fft_kernel<1024, false, 7>, (const void *)fft_kernel<1024, false, 8>,
-                              (const void *)fft_kernel<1024, false, 9>};
+                              (const void *)fft_kernel<1024, false, 9>, (const void *)fft_kernel<1024, true, 12, true>};
         for (const void *f : inst) SDRX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_fft_attr[dev] = true;
     }
-    if (!g_fft_tw[dev][log2n]) {
+    FftTable &t = g_fft_tw[dev][log2n];
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    if (!t.p) {
+        if (capturing) {
+            (void)hipGetLastError();
+            set_error("sdrx_fft_dev: the first call for %u points on a device allocates its twiddle table, which a stream capture "
+                      "forbids: call sdrx_init() (or make one uncaptured call) first", 1u << log2n);
+            return SDRX_EUNSUPPORTED;
+        }
         const unsigned N = 1u << log2n;
         v2d *p = nullptr;
-        SDRX_HIP(hipMalloc(&p, sizeof(v2d) * (N / 2)));
+        hipEvent_t ev = nullptr;
+        SDRX_HIP(hipMalloc(&p, sizeof(v2d) * (N / 2 ? N / 2 : 1)));
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipFree(p);
+            set_error("sdrx_fft_dev: event creation failed");
+            return SDRX_EHIP;
+        }
         fft_twiddle_kernel<<<(N / 2 + 255) / 256, 256, 0, s>>>(p, N);
         SDRX_HIP(hipGetLastError());
-        SDRX_HIP(hipStreamSynchronize(s)); // later calls may come on other streams
-        g_fft_tw[dev][log2n] = p;
+        SDRX_HIP(hipEventRecord(ev, s));
+        t.p = p;
+        t.filled = ev;
+    } else if (!t.done) {
+        if (hipEventQuery(t.filled) == hipSuccess) t.done = true;
+        else {
+            (void)hipGetLastError();
+            if (capturing) {
+                set_error("sdrx_fft_dev: the twiddle table of %u points is still being filled on another stream", 1u << log2n);
+                return SDRX_EUNSUPPORTED;
+            }
+            SDRX_HIP(hipStreamWaitEvent(s, t.filled, 0));
+        }
     }
-    *out = g_fft_tw[dev][log2n];
+    *out = t.p;
     return SDRX_OK;
+}
+
+// ---- longer transforms (any power of two above SDRX_FFT_MAX): the recursion of FFT.cpp:9-29 is the bit-reversal permutation
+// followed by log2 N butterfly stages.  After the permutation the first 12 stages stay inside blocks of 4096 consecutive
+// points (each block IS a 4096-point transform without its own permutation: the LDS kernel, NOREV); the remaining stages pair
+// points 2^s >= 4096 apart and run from global memory, three at a time on 8 points per thread (every access coalesced: a
+// thread's points lie 2^st apart, neighbouring threads' next to them), their twiddles std::polar(1, -2 PI k / len) evaluated
+// on the fly with the expression, and therefore the bits, of the table (sdrx_sincos).
+__global__ void __launch_bounds__(256) fft_bitrev_kernel(v2d *x, unsigned log2n)
+{
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= (1u << log2n)) return;
+    const unsigned r = __brev(p) >> (32 - log2n);
+    if (p < r) {
+        const v2d a = x[p], b = x[r];
+        x[p] = b;
+        x[r] = a;
+    }
+}
+
+template <int R> __global__ void __launch_bounds__(256) fft_global_stages_kernel(v2d *x, unsigned st, unsigned log2n)
+{
+    constexpr unsigned E = 1u << R;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= ((1u << log2n) >> R)) return;
+    const unsigned half = 1u << st, lo = t & (half - 1);
+    const size_t base = ((size_t)(t >> st) << (st + R)) + lo;
+    v2d v[E];
+#pragma unroll
+    for (unsigned q = 0; q < E; q++) v[q] = x[base + ((size_t)q << st)];
+#pragma unroll
+    for (unsigned r = 0; r < (unsigned)R; r++) { // stage st + r: len = 2^(st + r + 1), k = position inside the half
+        const double len = (double)(2ull << (st + r));
+#pragma unroll
+        for (unsigned ql = 0; ql < (1u << r); ql++) {
+            const unsigned k = lo + (ql << st);
+            const double theta = -2 * 3.141592653589793238460 * (double)k / len;
+            double sn, cs;
+            sdrx_sincos(theta, &sn, &cs);
+#pragma unroll
+            for (unsigned qh = 0; qh < (E >> (r + 1)); qh++) {
+                const unsigned q = (qh << (r + 1)) | ql;
+                const v2d o = v[q | (1u << r)], e = v[q];
+                const double tr = cs * o.x - sn * o.y, ti = cs * o.y + sn * o.x;
+                v[q] = v2d{e.x + tr, e.y + ti};
+                v[q | (1u << r)] = v2d{e.x - tr, e.y - ti};
+            }
+        }
+    }
+#pragma unroll
+    for (unsigned q = 0; q < E; q++) x[base + ((size_t)q << st)] = v[q];
 }
 
 int check_rows(const void *p, size_t n, size_t nchan, size_t pitch, const char *who)
@@ -637,6 +724,17 @@ void fold_channels(size_t nchan, unsigned &gy, unsigned &gz)
 }
 
 } // namespace
+
+// sdrx_init(): every table of the current device, on the null stream
+int fft_warm_tables()
+{
+    for (unsigned l = 1; l <= (unsigned)FFT_MAX_LOG2; l++) {
+        const v2d *tw = nullptr;
+        const int rc = fft_twiddles(l, nullptr, &tw);
+        if (rc != SDRX_OK) return rc;
+    }
+    return SDRX_OK;
+}
 } // namespace sdrx
 
 using namespace sdrx;
@@ -767,13 +865,34 @@ extern "C" int sdrx_fft_dev(double *iq, size_t n, size_t nchan, size_t pitch, vo
 {
     int r = check_rows(iq, n, nchan, pitch, "sdrx_fft_dev");
     if (r) return r < 0 ? r : SDRX_OK;
-    if (n & (n - 1) || n > SDRX_FFT_MAX) {
-        set_error("sdrx_fft_dev: length %zu is not a power of two <= %d", n, SDRX_FFT_MAX);
+    if (n & (n - 1) || n > ((size_t)1 << SDRX_FFT_MAX_LOG2_ANY)) {
+        set_error("sdrx_fft_dev: length %zu is not a power of two <= 2^%d", n, SDRX_FFT_MAX_LOG2_ANY);
         return SDRX_EUNSUPPORTED;
     }
     if (n == 1) return SDRX_OK;
     unsigned log2n = 0;
     while ((1ull << log2n) < n) log2n++;
+    if (n > SDRX_FFT_MAX) { // permutation, 4096-point blocks in LDS, the upper stages from global memory (see above)
+        hipStream_t s = (hipStream_t)stream;
+        const v2d *tw = nullptr;
+        int rc = fft_twiddles(FFT_MAX_LOG2, s, &tw);
+        if (rc != SDRX_OK) return rc;
+        const size_t blocks = n >> FFT_MAX_LOG2;
+        if (blocks > 0xffffffffull) return SDRX_EUNSUPPORTED;
+        const size_t lds = (SDRX_FFT_MAX / 2 + SDRX_FFT_MAX) * sizeof(v2d);
+        const unsigned grid = (unsigned)(blocks < 256 ? blocks : 256); // one workgroup per CU (LDS), each looping over its blocks
+        for (size_t c = 0; c < nchan; c++) {
+            v2d *row = reinterpret_cast<v2d *>(iq) + c * pitch;
+            fft_bitrev_kernel<<<(unsigned)(n / 256), 256, 0, s>>>(row, log2n);
+            fft_kernel<1024, true, 12, true><<<grid, 1024, lds, s>>>((double *)row, tw, FFT_MAX_LOG2, 0, SDRX_FFT_MAX, (unsigned)blocks);
+            unsigned st = FFT_MAX_LOG2;
+            for (; st + 3 <= log2n; st += 3) fft_global_stages_kernel<3><<<(unsigned)((n / 8 + 255) / 256), 256, 0, s>>>(row, st, log2n);
+            if (log2n - st == 2) fft_global_stages_kernel<2><<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(row, st, log2n);
+            if (log2n - st == 1) fft_global_stages_kernel<1><<<(unsigned)((n / 2 + 255) / 256), 256, 0, s>>>(row, st, log2n);
+        }
+        SDRX_HIP(hipGetLastError());
+        return SDRX_OK;
+    }
     const v2d *tw = nullptr;
     int rc = fft_twiddles(log2n, (hipStream_t)stream, &tw);
     if (rc != SDRX_OK) return rc;

@@ -134,6 +134,7 @@ int launch_psk_ambiguity_hits(int kind, uint8_t *decisions, size_t m, size_t nch
                               sdrx_psk_state *states, unsigned long long *hits, size_t max_hits, hipStream_t s);
 int launch_psk_modulate(int kind, const uint8_t *sym, size_t len, double *out_re, double *out_im, size_t zero_prefix,
                         hipStream_t s);
+int fft_warm_tables(); // dsp_kernels.hip: every twiddle table (64 ... 4096 points) of the current device, for sdrx_init()
 const double *psk_mf_taps_dev(); // RRC reversed (h[k] = RRC[128-k]), device resident, created on first use
 extern const double RRC_COEFF[129];
 

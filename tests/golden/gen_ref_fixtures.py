@@ -175,5 +175,19 @@ y = out["dsp_in"].copy()
 R.ref_dc_block(y, y, 257, 0.995)
 out["dsp_dc_block_inplace"] = y
 
+# ==== round 3 addition: fft above 4096 points (FFT.cpp:9-29 recurses for any power of two).  Inputs are regenerated from the
+# seed by the tests; 8192 points are kept whole, of 65536 every 8th output and the sha256 of all of them.
+import hashlib  # noqa: E402
+
+rng3 = np.random.default_rng(20260303)
+for n in (8192, 65536):
+    z = (rng3.normal(0, 1, n) + 1j * rng3.normal(0, 1, n)).astype(np.complex128)
+    R.ref_fft(z.view(np.float64), n)
+    if n == 8192:
+        out["dsp_fft_8192"] = z
+    else:
+        out["dsp_fft_65536_every8"] = z[::8].copy()
+        out["dsp_fft_65536_sha256"] = np.frombuffer(hashlib.sha256(z.tobytes()).digest(), dtype=np.uint8).copy()
+
 np.savez_compressed(os.path.join(HERE, "ref_fixtures.npz"), **out)
 print("wrote", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "ref_fixtures.npz")), "bytes")

@@ -682,13 +682,31 @@ def test_dsp_fft_many_rows(n, nchan, tune):
         assert torch.equal(torch.view_as_real(zd), torch.view_as_real(zd[:m][idx].contiguous())), (nt, ct)
 
 
+@pytest.mark.parametrize("log2n,nchan", [(13, 3), (14, 2), (15, 1), (16, 1), (17, 2), (18, 1), (20, 1)])
+def test_dsp_fft_longer_than_lds(log2n, nchan):
+    """fft() above 4096 points (FFT.cpp:9-29 recurses for any power of two): permutation + 4096-point blocks in LDS + the
+    upper stages (1, 2 or 3 at a time) from global memory; every row bit-identical to the oracle's recursion in shared-math
+    mode, rows at a pitch larger than n untouched between them, and within 1e-12 x log2 N of numpy's transform."""
+    n = 1 << log2n
+    rng = np.random.default_rng(log2n)
+    z = (rng.normal(0, 1, (nchan, n)) + 1j * rng.normal(0, 1, (nchan, n))).astype(np.complex128)
+    pitch = n + 16
+    buf = torch.full((nchan, pitch), 7.0 - 3.0j, dtype=torch.complex128, device="cuda")
+    buf[:, :n] = torch.tensor(z, device="cuda")
+    _lib.check(_lib.lib().sdrx_fft_dev(C.c_void_p(buf.data_ptr()), n, nchan, pitch, None), "sdrx_fft_dev")
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()
+    assert np.all(got[:, n:] == 7.0 - 3.0j)
+    for c in range(nchan):
+        want = O.fft(z[c], O.MATH_SHARED)
+        assert np.array_equal(got[c, :n], want), (log2n, c)
+        assert np.max(np.abs(want - np.fft.fft(z[c]))) <= 1e-12 * log2n * np.abs(want).max()
+
+
 def test_dsp_unsupported_and_empty():
     z = torch.zeros(2, 12, dtype=torch.complex128, device="cuda")
     with pytest.raises(RuntimeError):
         device.fft(z)  # not a power of two
-    z = torch.zeros(1, 8192, dtype=torch.complex128, device="cuda")
-    with pytest.raises(RuntimeError):
-        device.fft(z)  # beyond SDRX_FFT_MAX
     e = torch.zeros(0, 16, dtype=torch.float64, device="cuda")
     device.iir(device.IIR_DC_BLOCK, 0.995, e)
     device.normalize(e, torch.zeros(0, dtype=torch.float64, device="cuda"))

@@ -69,6 +69,46 @@ def test_dsp_primitive_fixtures():
     assert np.max(np.abs(O.fft(z, O.MATH_SHARED) - F["dsp_fft"])) <= 1e-12 * 8 * np.abs(F["dsp_fft"]).max()
 
 
+def _long_fft_inputs():
+    rng3 = np.random.default_rng(20260303)  # gen_ref_fixtures.py's round-3 generator, same draw order
+    return {n: (rng3.normal(0, 1, n) + 1j * rng3.normal(0, 1, n)).astype(np.complex128) for n in (8192, 65536)}
+
+
+def test_long_fft_fixtures():
+    """fft above 4096 points, pinned to the compiled reference (FFT.cpp:9-29): the oracle in libm mode reproduces its 8192
+    and 65536-point outputs bit for bit (the latter through every 8th value and the sha256 of all of them); the
+    shared-math mode, which the device computes, within 1e-12 x log2 N of the largest bin."""
+    import hashlib
+    zs = _long_fft_inputs()
+    a = O.fft(zs[8192], O.MATH_LIBM)
+    assert np.array_equal(a, F["dsp_fft_8192"])
+    b = O.fft(zs[65536], O.MATH_LIBM)
+    assert np.array_equal(b[::8], F["dsp_fft_65536_every8"])
+    assert np.array_equal(np.frombuffer(hashlib.sha256(b.tobytes()).digest(), dtype=np.uint8), F["dsp_fft_65536_sha256"])
+    for n, want in ((8192, a), (65536, b)):
+        got = O.fft(zs[n], O.MATH_SHARED)
+        assert np.max(np.abs(got - want)) <= 1e-12 * np.log2(n) * np.abs(want).max()
+
+
+@pytest.mark.gpu
+def test_device_long_fft_against_reference_fixtures():
+    """sdrx_fft_dev at 8192 and 65536 points against the reference's outputs: within 1e-12 x log2 N of the largest bin
+    (the twiddles are sdrx_math.h's, not libm's), and bit for bit against the oracle in shared-math mode."""
+    import torch
+    from sdr_amd import device
+    device.init(0)
+    zs = _long_fft_inputs()
+    for n in (8192, 65536):
+        zd = torch.tensor(zs[n][None, :], device="cuda")
+        device.fft(zd)
+        got = zd[0].cpu().numpy()
+        assert np.array_equal(got, O.fft(zs[n], O.MATH_SHARED))
+        if n == 8192:
+            assert np.max(np.abs(got - F["dsp_fft_8192"])) <= 1e-12 * 13 * np.abs(F["dsp_fft_8192"]).max()
+        else:
+            assert np.max(np.abs(got[::8] - F["dsp_fft_65536_every8"])) <= 1e-12 * 16 * np.abs(F["dsp_fft_65536_every8"]).max()
+
+
 def test_u8_ingest_fixture():
     """orc_u8_* against what Baseband_Stream::load_buffer / load_buffer_and_rotate90 produced (every byte value on both
     rails): the `char` reading, the 127.4 bias and rotate_90's byte order are the reference's, not a reading of them."""
