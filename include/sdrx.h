@@ -118,7 +118,12 @@ typedef struct sdrx_fir_job {
                                  decision against a rigorous error bound; outputs inside the bound are recomputed in the
                                  reference's fp64 order, so the bits are those of the exact path for every input (a table
                                  that is not the rounded taps is detected on the device and only costs time) */
+    void *am_work;            /* optional (NULL = absent), with taps_f32: device, SDRX_FIR_AM_WORK_BYTES the library may write
+                                 during the call (one buffer per concurrently running job).  With it, tiles whose samples
+                                 are 8-bit integers (a radio's) are filtered on the int8 matrix cores with fixed-point taps
+                                 the call derives from `taps`, verified and recomputed like the fp32 form: the same bits */
 } sdrx_fir_job;
+#define SDRX_FIR_AM_WORK_BYTES 16384
 
 /* Filter::execute (filt.cpp:267-273) on 1 rail (out0) or on I and Q (out0, out1), optionally
  * keeping every D-th output (decimate<T>, Resample.h:33-52).  Output type double. */

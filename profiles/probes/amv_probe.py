@@ -72,7 +72,7 @@ print("split equal", bool(torch.equal(outs[0], outs[1])), bool(torch.equal(outs[
 for gen in ("ook", "fm"):
     n = 1 << 28
     x = ook(n, 7) if gen == "ook" else bench.synth_fm_stream(torch, n, 1000, dev)
-    for amv, nb in ((3, 4), (3, 2), (2, 4), (0, 4)):
+    for amv, nb in ((4, 2), (1, 2), (3, 4), (3, 2), (2, 4), (0, 4)):
         L.sdrx_tune(b"SDRX_FIR_AMV", str(amv).encode())
         L.sdrx_tune(b"SDRX_AMV_NB", str(nb).encode())
         L.sdrx_tune(b"SDRX_AMV_STATS", b"0")

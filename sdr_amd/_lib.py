@@ -17,6 +17,9 @@ _vp = C.c_void_p
 _sz = C.c_size_t
 
 
+FIR_AM_WORK_BYTES = 16384  # SDRX_FIR_AM_WORK_BYTES
+
+
 class FirJob(C.Structure):
     """sdrx_fir_job"""
 
@@ -28,7 +31,7 @@ class FirJob(C.Structure):
         ("state_in", _vp), ("state_out", _vp), ("state_pitch", _sz),
         ("out0", _vp), ("out1", _vp), ("out_pitch", _sz), ("n_out", _sz),
         ("stream", _vp), ("dtype", C.c_int), ("u8_flags", C.c_int), ("u8_bias", C.c_double),
-        ("n_before", _sz), ("taps_f32", _vp),
+        ("n_before", _sz), ("taps_f32", _vp), ("am_work", _vp),
     ]
 
 

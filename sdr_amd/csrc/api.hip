@@ -219,9 +219,11 @@ extern "C" const char *sdrx_last_kernel(void)
             snprintf(one, sizeof(one), "fir_tile_kernel<R=%d, %s, %s, T=64, D=1 compile-time>", k.a, lay[k.b & 3], epi[k.c % 3]);
         else if (strncmp(k.family, "fir_amv_", 8) == 0)
         {
-            const bool mm = strncmp(k.family, "fir_amv_mfma", 12) == 0;
-            snprintf(one, sizeof(one), "%s<%s=%d, %s, EPI_AM verified, fp32 %s%s>", mm ? "fir_amv_mfma_kernel" : "fir_amv_kernel", mm ? "NB" : "R",
-                     k.a, lay[k.b & 3], mm ? "mfma 16x16x4" : "fma", strstr(k.family, "_ct64") ? ", T=64 compile-time" : "");
+            const bool mm = strncmp(k.family, "fir_amv_mfma", 12) == 0, i8 = strncmp(k.family, "fir_amv_i8", 10) == 0;
+            snprintf(one, sizeof(one), "%s<%s=%d, %s, EPI_AM verified, %s%s>", i8 ? "fir_amv_i8_kernel" : (mm ? "fir_amv_mfma_kernel" : "fir_amv_kernel"),
+                     mm || i8 ? "NB" : "R", k.a, lay[k.b & 3],
+                     i8 ? "int8 mfma 16x16x64 on 8-bit integer tiles (fixed-point taps), fp32 mfma 16x16x4 on the others" : (mm ? "fp32 mfma 16x16x4" : "fp32 fma"),
+                     strstr(k.family, "_ct64") ? ", T=64 compile-time" : "");
         }
         else if (strncmp(k.family, "psk_loops", 9) == 0)
             snprintf(one, sizeof(one), "%s<%s>", k.family, k.a == SDRX_BPSK ? "BPSK" : "QPSK");

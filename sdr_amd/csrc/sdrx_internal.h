@@ -40,7 +40,7 @@ struct Tuning {
     int fir_nt = 256;         // SDRX_FIR_NT: lanes per workgroup tile
     int fir_lds_soft_kb = 64; // SDRX_FIR_LDS_SOFT_KB: preferred LDS per workgroup tile
     int fir_fill = 1;         // SDRX_FIR_FILL: 0 = interior tiles stage through the general (bounds-tested) path too
-    int fir_amv = 1;          // SDRX_FIR_AMV: 0 = sdrx_fir_am_dev never takes the verified fp32 kernels; 1 auto; 2 the packed-fma form; 3 the matrix-core form
+    int fir_amv = 1;          // SDRX_FIR_AMV: 0 = sdrx_fir_am_dev never takes the verified fp32 kernels; 1 auto; 2 the packed-fma form; 3 the fp32 matrix-core form; 4 the int8 matrix-core form (where the job has am_work)
     int amv_nb = 2;           // SDRX_AMV_NB: blocks of 256 outputs per wave of fir_amv_mfma_kernel (2 or 4)
     int amv_dbg = 0;          // SDRX_AMV_DBG: timing experiments (wrong results)
     int amv_stats = 0;        // SDRX_AMV_STATS: 1 = fir_amv_kernel counts its recomputed outputs (sdrx_fir_am_verify_stats)

@@ -49,6 +49,8 @@ class FirChain:
         self.taps = torch.from_numpy(taps).to(self.device).to(dtype)
         # the taps rounded to float: with them sdrx_fir_am_dev filters in fp32 and verifies every decision (same bits)
         self.taps_f32 = torch.from_numpy(taps.astype(np.float32)).to(self.device) if dtype == torch.float64 else None
+        # ... and a work buffer for the plan of its int8 form (tiles of 8-bit integer samples: the matrix cores)
+        self.am_work = torch.zeros(_lib.FIR_AM_WORK_BYTES, dtype=torch.uint8, device=self.device) if dtype == torch.float64 else None
         self.pitch = int(self.L.sdrx_fir_state_doubles(self.T))
         self.state = [torch.zeros(self.nchan, self.pitch, dtype=dtype, device=self.device) for _ in range(2)]
         self.cur = 0
@@ -80,6 +82,7 @@ class FirChain:
         j.dtype = _lib.F32 if self.dtype == torch.float32 else _lib.F64
         j.u8_bias, j.u8_flags = self.u8_bias, self.u8_flags
         j.taps_f32 = _ptr(self.taps_f32)
+        j.am_work = _ptr(self.am_work)
         return j
 
     def _run(self, fn, name, layout, in0, in1, n, in_pitch, out0, out1, out_pitch, fast_fma=False, n_out=0):
@@ -143,6 +146,7 @@ class FirRing:
         self.chain, self.x, self.out = chain, x, out
         layout, in0, in1, n, pitch = chain._inputs(x[0:1])
         assert in1 is None
+        _need(out.dim() == 2 and out.shape[1] >= chain.n_out(n), "FirRing: out must be (chunks, >= %d)" % chain.n_out(n))
         j = chain._job(layout, x[0:1], None, n, pitch, out[0:1], None, out.shape[1], False, 0)
         j.stream = None
         self.L = _lib.lib()
@@ -200,6 +204,7 @@ def am_modulate(bits, out, len_mod=None):
     assert bits.dtype == torch.uint8 and bits.dim() == 2 and bits.is_contiguous()
     assert out.dtype == torch.float64 and out.dim() == 2 and out.is_contiguous() and out.shape[0] == bits.shape[0]
     len_mod = out.shape[1] if len_mod is None else int(len_mod)
+    _need(0 <= len_mod <= out.shape[1], "am_modulate: len_mod beyond the output rows")
     _lib.check(_lib.lib().sdrx_am_modulate_dev(_ptr(bits), bits.shape[1], bits.shape[0], bits.shape[1], _ptr(out), len_mod,
                                                out.shape[1], _stream()), "sdrx_am_modulate_dev")
     return out
@@ -227,6 +232,12 @@ def fm_modulate(bits, w_mark, w_space, out):
 
 def fm_convolve(x, w, out, ds):
     """FM<T>::convolve (repaired): out[k] += sum_j x[(k+1)ds-1-j] * w[len2-1-j]; 1-D float64 device tensors."""
+    ds = int(ds)
+    _need(ds >= 1, "fm_convolve: ds must be >= 1")
+    for t in (x, w, out):
+        _need(t.dtype == torch.float64 and t.is_contiguous(), "fm_convolve: contiguous float64 tensors")
+    n_out = (x.numel() - ds + 1 + ds - 1) // ds if x.numel() >= ds else 0  # outputs at ds-1, 2ds-1, ... < len1
+    _need(out.numel() >= n_out, "fm_convolve: out must hold %d doubles" % n_out)
     _lib.check(_lib.lib().sdrx_fm_convolve_dev(_ptr(x), x.numel(), _ptr(w), w.numel(), _ptr(out), int(ds), _stream()),
                "sdrx_fm_convolve_dev")
     return out
@@ -292,6 +303,8 @@ def rtlfm_low_pass_real(pcm, rate_out, rate_out2, post_state, lpr_state):
     RtlFmFull keeps it (row length at [:, 3], updated); lpr_state (nchan, 2) int32 = now_lpr, prev_lpr_index."""
     assert pcm.dtype == torch.int16 and pcm.dim() == 2 and pcm.is_contiguous()
     assert post_state.dtype == torch.int32 and lpr_state.dtype == torch.int32 and lpr_state.numel() == 2 * pcm.shape[0]
+    _need(post_state.is_contiguous() and post_state.numel() >= 4 * pcm.shape[0] and lpr_state.is_contiguous(),
+          "rtlfm_low_pass_real: post_state must be (nchan, 4), both state tensors contiguous")
     _lib.check(_lib.lib().sdrx_rtlfm_low_pass_real_dev(_ptr(pcm), pcm.shape[0], pcm.shape[1], int(rate_out), int(rate_out2),
                                                        _ptr(post_state), _ptr(lpr_state), _stream()),
                "sdrx_rtlfm_low_pass_real_dev")

@@ -52,8 +52,8 @@ def test_struct_layouts(lib):
     from sdr_amd import _lib
     assert C.sizeof(_lib.PskState) == 24 * 8 + 6 * 4 + 4 * 64 * 8
     assert _lib.PskState.uw.offset == 24 * 8 + 24
-    assert C.sizeof(_lib.FirJob) == 8 + 2 * 8 + 3 * 8 + 8 + 8 + 3 * 8 + 2 * 8 + 2 * 8 + 8 + 8 + 8 + 8 + 8  # ... stream, dtype, u8_flags, u8_bias, n_before, taps_f32
-    assert _lib.FirJob.dtype.offset == 128 and _lib.FirJob.taps_f32.offset == 152
+    assert C.sizeof(_lib.FirJob) == 8 + 2 * 8 + 3 * 8 + 8 + 8 + 3 * 8 + 2 * 8 + 2 * 8 + 8 + 8 + 8 + 8 + 8 + 8  # ... stream, dtype, u8_flags, u8_bias, n_before, taps_f32, am_work
+    assert _lib.FirJob.dtype.offset == 128 and _lib.FirJob.taps_f32.offset == 152 and _lib.FirJob.am_work.offset == 160
     assert lib.sdrx_fir_state_doubles(64) == 128
 
 

@@ -2,7 +2,8 @@
 the oracle's chain -- Filter::execute on I and Q (filt.cpp:248-273) + AM<T>::demodulate (AM.h:63-77) -- on inputs
 ENGINEERED to sit on the decision threshold, on non-finite and extreme samples, with a wrong fp32 tap table, and
 streamed in ragged chunks.  Bar: every bit equal to the oracle's, in every form (SDRX_FIR_AMV = 0 exact fp64 kernel,
-2 packed fma, 3 matrix cores with 2 and 4 blocks per wave, 1 the default choice)."""
+2 packed fma, 3 fp32 matrix cores with 2 and 4 blocks per wave, 4 int8 matrix cores on the tiles that are 8-bit integers,
+1 the default choice)."""
 import ctypes as C
 
 import numpy as np
@@ -18,7 +19,7 @@ torch = pytest.importorskip("torch")
 from sdr_amd import _lib, device  # noqa: E402
 
 L = O.lib()
-FORMS = [(0, 4), (1, None), (2, 4), (3, 2), (3, 4)]  # (SDRX_FIR_AMV, SDRX_AMV_NB)
+FORMS = [(0, 4), (1, None), (2, 4), (3, 2), (3, 4), (4, None)]  # (SDRX_FIR_AMV, SDRX_AMV_NB); 4 = the int8 matrix form
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -67,10 +68,12 @@ def _run_forms(tune, taps, re_rows, im_rows, want_rows, min_recomputed=0, split=
             assert "fir_amv_kernel" in kern, kern
         elif form == 3:
             assert "fir_amv_mfma_kernel" in kern and "NB=%d" % nb in kern, kern
+        elif form == 4:
+            assert "fir_amv_i8_kernel" in kern, kern
         bad = np.argwhere(got != want_rows)
         assert bad.size == 0, (form, nb, kern, bad[:5])
         st = _stats()
-        if form in (2, 3):
+        if form in (2, 3, 4):
             assert st[0] >= min_recomputed, (form, nb, st)
     return st
 
@@ -194,3 +197,92 @@ def test_verified_forms_streamed_in_ragged_chunks(T, tune):
         torch.cuda.synchronize()
         g = got[0].cpu().numpy()
         assert np.array_equal(g, want), (form, nb, np.flatnonzero(g != want)[:5])
+
+
+def test_int8_form_on_integer_streams_and_mixed_tiles(tune):
+    """The int8 matrix form (fixed-point taps, exact integer products) on what it is for -- 8-bit integer samples -- and on
+    streams where only SOME tiles are: integer OOK with fractions / +-128 / 200 / NaN dropped into chosen tiles, a stream
+    that starts integer and turns fractional half way (the call's probe says 'int8', the tiles decide), several channels,
+    interleaved and split rails, ragged length.  Every bit equals the oracle's; the integer tiles did take the int8 path
+    (stats[3] counts them)."""
+    err, taps = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
+    n = 6 * 2048 + 1234
+    # the plan kernel probes sample floor(u n / 1024) of channel u % nchan, u = 0 .. 1023: the anomalies go where it does not look
+    probed = {c: {(u * n) // 1024 for u in range(1024) if u % 5 == c} for c in range(5)}
+
+    def free(c, lo, k=1):  # the first run of k unprobed positions of channel c at or after lo
+        p = lo
+        while any(q in probed[c] for q in range(p, p + k)):
+            p += 1
+        return p
+    rows_re, rows_im = [], []
+    for c in range(5):
+        re, im, _ = ook_iq(n, seed=400 + c, ds=8)
+        re, im = np.round(re).clip(-127, 127), np.round(im).clip(-127, 127)
+        if c == 1:
+            re[free(c, 3000)] += 0.5   # one fraction: tile 1 takes the fp32 path
+            im[free(c, 9000)] = 128.0  # +-128 is outside the symmetric range: tile 4
+            re[free(c, 9001)] = -128.0
+        if c == 2:
+            p = free(c, 5000, 3)       # tile 2
+            im[p:p + 3] = [200.0, np.nan, 1e9]
+        if c == 3:
+            p = free(c, 2048 * 3 + 5, 20)
+            re[p:p + 20] += 0.25       # a run of fractions between two probed positions: tile 3
+        rows_re.append(re)
+        rows_im.append(im)
+    re, im = np.stack(rows_re), np.stack(rows_im)
+    with np.errstate(all="ignore"):
+        want = np.stack([_oracle_bits(taps, re[c], im[c]) for c in range(re.shape[0])])
+    tune("SDRX_AMV_STATS", 1)
+    tune("SDRX_FIR_AMV", 4)
+    for split in (False, True):
+        d_re, d_im = torch.tensor(re, device="cuda"), torch.tensor(im, device="cuda")
+        x = (d_re, d_im) if split else torch.stack([d_re, d_im], dim=-1).contiguous()
+        _stats()
+        ch = device.FirChain(taps, nchan=5, decim=1)
+        bits = torch.zeros(5, n, dtype=torch.uint8, device="cuda")
+        ch.fir_am(x, bits)
+        ch.fir_am(x, bits)  # a second call continues the streams: compare that one too
+        torch.cuda.synchronize()
+        assert "fir_amv_i8_kernel" in _lib.lib().sdrx_last_kernel().decode()
+        hI = [np.zeros(63) for _ in range(5)]
+        hQ = [np.zeros(63) for _ in range(5)]
+        with np.errstate(all="ignore"):
+            for c in range(5):
+                _oracle_bits(taps, re[c], im[c], hI[c], hQ[c])
+                w2 = _oracle_bits(taps, re[c], im[c], hI[c], hQ[c])
+                assert np.array_equal(bits[c].cpu().numpy(), w2), (split, c)
+        st = _stats()
+        # tiles 1 .. 5 of a channel are interior (tile 0 takes its history from the state rows, tile 6 is ragged); of those,
+        # channel 1 loses two to the fp32 path, channels 2 and 3 one each (an anomaly within 112 samples of a tile's start
+        # would take the tile before it along: none is); two calls
+        assert st[3] == 2 * (5 + 3 + 4 + 4 + 5), st
+
+
+@pytest.mark.parametrize("T", [16, 17, 49, 64, 65, 113, 129, 241, 242])
+def test_int8_form_filter_lengths(T, tune):
+    """Filter lengths around the int8 form's operand boundaries (T <= 64 NIT - 15: 49 | 50, 113 | 114, 177 | 178, 241 | 242;
+    beyond 241 taps the call falls back to the fp32 matrix form), taps of very different magnitudes (fixed point relative to
+    the largest), integer samples, two channels."""
+    rng = np.random.default_rng(T)
+    taps = rng.normal(0, 1, T) * np.exp(rng.uniform(-12, 0, T))  # magnitudes over five decades
+    n = 5 * 2048 + 77
+    re = rng.integers(-127, 128, (2, n)).astype(np.float64)
+    im = rng.integers(-127, 128, (2, n)).astype(np.float64)
+    env = np.abs(np.convolve(re[0] + 1j * im[0], taps)[T:n])
+    taps *= 80.0 / np.median(env)  # the envelope straddles the threshold: about half the bits are ones
+    want = np.stack([_oracle_bits(taps, re[c], im[c]) for c in range(2)])
+    assert 0.2 < want.mean() < 0.8
+    tune("SDRX_FIR_AMV", 4)
+    tune("SDRX_AMV_STATS", 1)
+    _stats()
+    ch = device.FirChain(taps, nchan=2, decim=1)
+    bits = torch.zeros(2, n, dtype=torch.uint8, device="cuda")
+    ch.fir_am(torch.tensor(np.stack([re, im], axis=-1), device="cuda"), bits)
+    torch.cuda.synchronize()
+    kern = _lib.lib().sdrx_last_kernel().decode()
+    assert ("fir_amv_i8_kernel" in kern) == (T <= 241), kern
+    assert np.array_equal(bits.cpu().numpy(), want)
+    st = _stats()
+    assert (st[3] > 0) == (T <= 241), st
