@@ -469,6 +469,11 @@ def rccl_gather_epilogue(torch, dist, shard, device, args, rank, world, dev, red
 # ------------------------------------------------------------------------------------------ one rank
 
 def worker(args):
+    # stdout carries ONE line, the JSON: everything else a library prints there (gloo announces its connections on stdout)
+    # goes to stderr.  The descriptor itself is switched, so native code is covered; the line is written to the saved one.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     sys.path.insert(0, ROOT)
     from sdr_amd import _lib, device, shard
@@ -573,7 +578,7 @@ def worker(args):
             res["cpu_baseline"] = cpu_baseline_cfg2(taps, D)
             threads = host_threads()
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(taps, D, threads, 25 if threads <= 16 else 23)
-        print(json.dumps(res), flush=True)
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:
         if rccl.get("rccl_error") == "timeout":
             sys.stdout.flush()

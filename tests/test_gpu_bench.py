@@ -29,6 +29,7 @@ def test_bench_spawns_two_ranks_on_sharded_cfg4():
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout.decode()
+    assert p.stdout.decode().strip().splitlines() == lines  # stdout is that line and nothing else (gloo's chatter goes to stderr)
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["steps"] == 3
     assert r["config"]["workload"].startswith("cfg4") and r["config"]["channels_per_gpu"] == 32
