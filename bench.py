@@ -65,6 +65,11 @@ def parse_args(argv=None):
                                                             "stays 2^26 samples); cfg4: total channels (default 1024)")
     ap.add_argument("--bpsk", action="store_true", help="cfg3: BPSK instead of QPSK")
     ap.add_argument("--fast-fma", action="store_true")
+    ap.add_argument("--spin-up-ms", type=float, default=250.0,
+                    help="untimed launches of the same step for this long BEFORE the W warm-up steps: the part's clocks take "
+                         "tens of milliseconds of sustained load to reach the state they hold in a running pipeline, and fall "
+                         "back within half a second of idling (profiles/probes/warm_order_probe.py).  0 = none.  The line "
+                         "reports the figure without it too (spin_up.cold_ms_per_step)")
     ap.add_argument("--mfma", action="store_true", help="cfg5: fp64 MFMA Toeplitz formulation (fast mode 2): cfg5's default")
     ap.add_argument("--exact", action="store_true",
                     help="cfg5: the VALU convolution with the CPU's two roundings per tap (bit-identical samples) instead of the "
@@ -299,8 +304,14 @@ def build_workload(wl, args, rank, world, dev):
     return w
 
 
-def timed_steps(torch, step, warmup, steps, barrier=None):
+def timed_steps(torch, step, warmup, steps, barrier=None, spin_up_s=0.0):
     """-> (wall seconds between the barriers, HIP-event milliseconds on the launch stream) for `steps` steps."""
+    if spin_up_s > 0:  # bring the device to its sustained state (same launches, untimed), then the warm-up steps as asked
+        t_end = time.perf_counter() + spin_up_s
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -515,7 +526,10 @@ def worker(args):
     barrier = None
     if dist is not None:  # (an all-reduce of one element on the reduction device: with the mixed backend dist.barrier()
         barrier = lambda: dist.all_reduce(torch.zeros(1, device=red_dev))  # noqa: E731   would bring up RCCL for nothing)
-    dt, ev_ms = timed_steps(torch, w["step"], args.warmup, args.steps, barrier)
+    cold_ms = None
+    if world == 1 and args.spin_up_ms > 0:  # the same measurement first thing, for the record (not the value)
+        cold_ms = timed_steps(torch, w["step"], args.warmup, args.steps)[1] / args.steps
+    dt, ev_ms = timed_steps(torch, w["step"], args.warmup, args.steps, barrier, args.spin_up_ms / 1e3)
     kernel = L.sdrx_last_kernel().decode()  # what the launcher picked for this shape (the last step's launches)
     dt = shard.max_over_ranks(dt, device=red_dev)
 
@@ -560,6 +574,9 @@ def worker(args):
             "config": w["cfg"],
             "roofline": roofline_of(wl, w, launch_s, kernel),
         }
+        res["spin_up"] = {"ms": args.spin_up_ms, "cold_ms_per_step": cold_ms,
+                          "what": "untimed launches of the same step before the W warm-up steps (device at the clocks it holds in a "
+                                  "running pipeline); cold_ms_per_step = the same W + K measurement first thing in the process"}
         if dist is not None:
             res.update({k: v for k, v in rccl.items() if k in ("rccl_ranks", "gather_ms")})
             res["rccl"] = dict(rccl, numa_node=numa_node, what="epilogue after the timed region: shard.gather_bits over RCCL, "
