@@ -288,3 +288,64 @@ def test_int8_form_filter_lengths(T, tune):
     assert np.array_equal(bits.cpu().numpy(), want)
     st = _stats()
     assert (st[3] > 0) == (T <= 241), st
+
+
+@pytest.mark.parametrize("T", [64, 129, 17])
+def test_verified_forms_from_the_radios_raw_bytes(T, tune):
+    """SDRX_IQ_U8 input with the plain conversion (byte - 127: rtlsdr_receiver.cpp:1587-1588): every verified form reads
+    the bytes directly (the int8 form filters them as the integers they are; a tile that holds a byte of 255 = +128 is
+    outside its symmetric range and takes the fp32 form), streamed over ragged calls incl. one that ends on a tile
+    boundary; every bit equals the oracle's chain on the converted samples.  Other conversions (bias 127.4, signed char,
+    rotate_90) keep the exact kernel."""
+    if T == 64:
+        err, taps = O.fir_design(O.LPF, T, 2.0e6, 1.0e5)
+    else:
+        err, taps = O.fir_design(O.LPF, T, 2.0e6, 1.0e5)
+        taps = taps * 1.1
+    n, nchan = 9 * 2048 + 333, 3
+    rng = np.random.default_rng(T)
+    raw = np.zeros((nchan, n, 2), dtype=np.uint8)
+    for c in range(nchan):
+        re, im, _ = ook_iq(n, seed=600 + c + T, ds=8)
+        raw[c, :, 0] = np.round(re).clip(-127, 127) + 127
+        raw[c, :, 1] = np.round(im).clip(-127, 127) + 127
+    raw[1, 5000, 0] = 255  # +128: tile 2 of channel 1 is not int8
+    raw[1, 5001, 1] = 0
+    raw[2, rng.integers(0, n, 40), 1] = rng.integers(0, 256, 40).astype(np.uint8)
+    x = raw.astype(np.float64) - 127.0
+    cuts = [0, 4096, 4096 + 8192, 4096 + 8192 + 777, n]
+    hI = [np.zeros(max(T - 1, 1)) for _ in range(nchan)]
+    hQ = [np.zeros(max(T - 1, 1)) for _ in range(nchan)]
+    want = np.stack([np.concatenate([_oracle_bits(taps, x[c, a:b, 0], x[c, a:b, 1], hI[c], hQ[c]) for a, b in zip(cuts[:-1], cuts[1:])])
+                     for c in range(nchan)])
+    assert 0.1 < want.mean() < 0.9
+    d_raw = torch.tensor(raw, device="cuda")
+    tune("SDRX_AMV_STATS", 1)
+    for form, nb in FORMS:
+        tune("SDRX_FIR_AMV", form)
+        tune("SDRX_AMV_NB", nb)
+        _stats()
+        ch = device.FirChain(taps, nchan=nchan, decim=1)
+        got = torch.zeros(nchan, n, dtype=torch.uint8, device="cuda")
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            o = torch.zeros(nchan, b - a, dtype=torch.uint8, device="cuda")
+            ch.fir_am(d_raw[:, a:b].contiguous(), o)
+            got[:, a:b] = o
+        torch.cuda.synchronize()
+        kern = _lib.lib().sdrx_last_kernel().decode()
+        assert ("fir_amv" in kern) == (form != 0) and "IQ_U8" in kern, (form, kern)
+        g = got.cpu().numpy()
+        assert np.array_equal(g, want), (form, nb, np.argwhere(g != want)[:5])
+        if form == 4:
+            assert _stats()[3] > 0
+    # another conversion: the exact kernel, still the oracle's bits
+    tune("SDRX_FIR_AMV", None)
+    ch = device.FirChain(taps, nchan=nchan, decim=1)
+    ch.set_u8_conversion(bias=127.4, signed_char=True)
+    o = torch.zeros(nchan, n, dtype=torch.uint8, device="cuda")
+    ch.fir_am(d_raw, o)
+    torch.cuda.synchronize()
+    assert "fir_amv" not in _lib.lib().sdrx_last_kernel().decode()
+    x2 = raw.view(np.int8).astype(np.float64) - 127.4
+    w2 = np.stack([_oracle_bits(taps, x2[c, :, 0], x2[c, :, 1]) for c in range(nchan)])
+    assert np.array_equal(o.cpu().numpy(), w2)
