@@ -118,110 +118,46 @@ SDRX_HD void sdrx_sincos(double x, double *s, double *c)
 /* ---- sincos, table form (the PSK carrier loop) ------------------------------ */
 
 /*
- * sdrx_sincos_tab: the same job as sdrx_sincos in about half the operations and a shorter dependent chain, for the one
+ * sdrx_sincos_tab: the same job as sdrx_sincos in a third of the operations and a much shorter dependent chain, for the one
  * caller where sincos sits inside a serial per-sample recurrence (BPSK.cpp:403-404, QPSK.cpp:365-366: the carrier loop).
- *   x = k * (pi/32) + r,  |r| <= pi/64:   sin x = S_k + (S_k (cos r - 1) + C_k sin r),   cos x = C_k + (C_k (cos r - 1) - S_k sin r)
- * with (S_k, C_k) = (sin, cos)(k pi/32) from a 64-entry table (sdr_amd/tools/gen_sincos_table.py; hexadecimal constants, so
- * every compiler reads the same doubles) and Taylor polynomials of degree 7 / 8 on the small argument (next terms
- * r^9/9! < 5e-18, r^10/10! < 3e-20).  The big term of each result is a table entry, the rest a correction below 0.05: the
- * result is within 1 ulp of the true value for |x| <= 1.5e6 (test_oracle_golden.py measures it against libm).  Like
- * everything in this file: IEEE operations in source order, the same bits on the host and on gfx950.
- * `tab`: 128 doubles {S_0, C_0, S_1, C_1, ...}; on the host SDRX_SINCOS_TAB, on the GPU the kernel's copy in LDS.
+ *   x = k * (pi/128) + r,  |r| <= pi/256:   sin x = (S_k + S_k (cos r - 1)) + C_k sin r,   cos x = (C_k + C_k (cos r - 1)) - S_k sin r
+ *   (each bracket and each sum one fma: two roundings of values below 1, so within 1 ulp of the true value)
+ * with (S_k, C_k) = (sin, cos)(k pi/128) from a 256-entry table (include/sdrx_sincos_table.h, written by
+ * sdr_amd/tools/gen_sincos_table.py; hexadecimal constants, so every compiler reads the same doubles) and Taylor polynomials
+ * of degree 5 / 6 on the small argument (next terms r^7/7! < 9e-18, r^8/8! < 2e-20).  Reduction: t = fma(x, 128/pi, 1.5 2^52)
+ * holds the nearest integer fn to x 128/pi in its low significand bits (k = those bits mod 256, no conversion), fn = t - 1.5 2^52,
+ * r = fma(-fn, Q2, fma(-fn, Q1, x)) with pi/128 = Q1 + Q2 to 2^-85: Q1 has 26 significant bits, so fn Q1 and the first
+ * difference are exact for |fn| < 2^27, and the second fma rounds once.  The result is within 1 ulp of the true value for |x| <= 1.5e6
+ * (test_oracle_golden.py measures it against libm).  Like everything in this file: IEEE operations in source order, the same bits on the host and on gfx950.
+ * `tab`: 512 doubles {S_0, C_0, S_1, C_1, ...}; on the host SDRX_SINCOS_TAB, on the GPU the kernel's copy in LDS.
  */
-#define SDRX_SINCOS_TAB_VALUES \
-    0x0.0p+0, 0x1.0000000000000p+0, /* k =  0 */ \
-    0x1.917a6bc29b42cp-4, 0x1.fd88da3d12526p-1, /* k =  1 */ \
-    0x1.8f8b83c69a60bp-3, 0x1.f6297cff75cb0p-1, /* k =  2 */ \
-    0x1.294062ed59f06p-2, 0x1.e9f4156c62ddap-1, /* k =  3 */ \
-    0x1.87de2a6aea963p-2, 0x1.d906bcf328d46p-1, /* k =  4 */ \
-    0x1.e2b5d3806f63bp-2, 0x1.c38b2f180bdb1p-1, /* k =  5 */ \
-    0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1, /* k =  6 */ \
-    0x1.44cf325091dd6p-1, 0x1.8bc806b151741p-1, /* k =  7 */ \
-    0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1, /* k =  8 */ \
-    0x1.8bc806b151741p-1, 0x1.44cf325091dd6p-1, /* k =  9 */ \
-    0x1.a9b66290ea1a3p-1, 0x1.1c73b39ae68c8p-1, /* k = 10 */ \
-    0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63bp-2, /* k = 11 */ \
-    0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2, /* k = 12 */ \
-    0x1.e9f4156c62ddap-1, 0x1.294062ed59f06p-2, /* k = 13 */ \
-    0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60bp-3, /* k = 14 */ \
-    0x1.fd88da3d12526p-1, 0x1.917a6bc29b42cp-4, /* k = 15 */ \
-    0x1.0000000000000p+0, 0x0.0p+0, /* k = 16 */ \
-    0x1.fd88da3d12526p-1, -0x1.917a6bc29b42cp-4, /* k = 17 */ \
-    0x1.f6297cff75cb0p-1, -0x1.8f8b83c69a60bp-3, /* k = 18 */ \
-    0x1.e9f4156c62ddap-1, -0x1.294062ed59f06p-2, /* k = 19 */ \
-    0x1.d906bcf328d46p-1, -0x1.87de2a6aea963p-2, /* k = 20 */ \
-    0x1.c38b2f180bdb1p-1, -0x1.e2b5d3806f63bp-2, /* k = 21 */ \
-    0x1.a9b66290ea1a3p-1, -0x1.1c73b39ae68c8p-1, /* k = 22 */ \
-    0x1.8bc806b151741p-1, -0x1.44cf325091dd6p-1, /* k = 23 */ \
-    0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1, /* k = 24 */ \
-    0x1.44cf325091dd6p-1, -0x1.8bc806b151741p-1, /* k = 25 */ \
-    0x1.1c73b39ae68c8p-1, -0x1.a9b66290ea1a3p-1, /* k = 26 */ \
-    0x1.e2b5d3806f63bp-2, -0x1.c38b2f180bdb1p-1, /* k = 27 */ \
-    0x1.87de2a6aea963p-2, -0x1.d906bcf328d46p-1, /* k = 28 */ \
-    0x1.294062ed59f06p-2, -0x1.e9f4156c62ddap-1, /* k = 29 */ \
-    0x1.8f8b83c69a60bp-3, -0x1.f6297cff75cb0p-1, /* k = 30 */ \
-    0x1.917a6bc29b42cp-4, -0x1.fd88da3d12526p-1, /* k = 31 */ \
-    0x0.0p+0, -0x1.0000000000000p+0, /* k = 32 */ \
-    -0x1.917a6bc29b42cp-4, -0x1.fd88da3d12526p-1, /* k = 33 */ \
-    -0x1.8f8b83c69a60bp-3, -0x1.f6297cff75cb0p-1, /* k = 34 */ \
-    -0x1.294062ed59f06p-2, -0x1.e9f4156c62ddap-1, /* k = 35 */ \
-    -0x1.87de2a6aea963p-2, -0x1.d906bcf328d46p-1, /* k = 36 */ \
-    -0x1.e2b5d3806f63bp-2, -0x1.c38b2f180bdb1p-1, /* k = 37 */ \
-    -0x1.1c73b39ae68c8p-1, -0x1.a9b66290ea1a3p-1, /* k = 38 */ \
-    -0x1.44cf325091dd6p-1, -0x1.8bc806b151741p-1, /* k = 39 */ \
-    -0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1, /* k = 40 */ \
-    -0x1.8bc806b151741p-1, -0x1.44cf325091dd6p-1, /* k = 41 */ \
-    -0x1.a9b66290ea1a3p-1, -0x1.1c73b39ae68c8p-1, /* k = 42 */ \
-    -0x1.c38b2f180bdb1p-1, -0x1.e2b5d3806f63bp-2, /* k = 43 */ \
-    -0x1.d906bcf328d46p-1, -0x1.87de2a6aea963p-2, /* k = 44 */ \
-    -0x1.e9f4156c62ddap-1, -0x1.294062ed59f06p-2, /* k = 45 */ \
-    -0x1.f6297cff75cb0p-1, -0x1.8f8b83c69a60bp-3, /* k = 46 */ \
-    -0x1.fd88da3d12526p-1, -0x1.917a6bc29b42cp-4, /* k = 47 */ \
-    -0x1.0000000000000p+0, 0x0.0p+0, /* k = 48 */ \
-    -0x1.fd88da3d12526p-1, 0x1.917a6bc29b42cp-4, /* k = 49 */ \
-    -0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60bp-3, /* k = 50 */ \
-    -0x1.e9f4156c62ddap-1, 0x1.294062ed59f06p-2, /* k = 51 */ \
-    -0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2, /* k = 52 */ \
-    -0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63bp-2, /* k = 53 */ \
-    -0x1.a9b66290ea1a3p-1, 0x1.1c73b39ae68c8p-1, /* k = 54 */ \
-    -0x1.8bc806b151741p-1, 0x1.44cf325091dd6p-1, /* k = 55 */ \
-    -0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1, /* k = 56 */ \
-    -0x1.44cf325091dd6p-1, 0x1.8bc806b151741p-1, /* k = 57 */ \
-    -0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1, /* k = 58 */ \
-    -0x1.e2b5d3806f63bp-2, 0x1.c38b2f180bdb1p-1, /* k = 59 */ \
-    -0x1.87de2a6aea963p-2, 0x1.d906bcf328d46p-1, /* k = 60 */ \
-    -0x1.294062ed59f06p-2, 0x1.e9f4156c62ddap-1, /* k = 61 */ \
-    -0x1.8f8b83c69a60bp-3, 0x1.f6297cff75cb0p-1, /* k = 62 */ \
-    -0x1.917a6bc29b42cp-4, 0x1.fd88da3d12526p-1, /* k = 63 */
+#include "sdrx_sincos_table.h"
 
 #if !defined(__HIP_DEVICE_COMPILE__)
-static const double SDRX_SINCOS_TAB[128] = {SDRX_SINCOS_TAB_VALUES};
+static const double SDRX_SINCOS_TAB[2 * SDRX_SINCOS_TAB_N] = {SDRX_SINCOS_TAB_VALUES};
 #endif
 
 /* The common case, straight-line (|x| <= 1.5e6); returns nonzero for every other x, as sdrx_sincos_core does. */
 SDRX_HD int sdrx_sincos_tab_core(double x, const double *tab, double *s, double *c)
 {
-    const double INV_STEP = 0x1.45f306dc9c883p+3; /* 32/pi */
-    /* pi/32 in 28 + 28 + 53 bits: x - fn*Q1 is exact for |fn| < 2^24 */
-    const double Q1 = 0x1.921fb54000000p-4, Q2 = 0x1.10b4610000000p-34, Q3 = 0x1.a62633145c06ep-62;
-    const double S1 = -1.0 / 6.0, S2 = 1.0 / 120.0, S3 = -1.0 / 5040.0;
-    const double C1 = 1.0 / 24.0, C2 = -1.0 / 720.0, C3 = 1.0 / 40320.0;
-    const double fn = rint(x * INV_STEP);
-    double r = SDRX_FMA(-fn, Q1, x);
-    r = SDRX_FMA(-fn, Q2, r);
-    r = SDRX_FMA(-fn, Q3, r);
-    const int k = (int)fn & 63; /* |fn| < 2^24 whenever the result is used */
+    const double MAGIC = 0x1.8p+52;
+    const double S1 = -1.0 / 6.0, S2 = 1.0 / 120.0;
+    const double C1 = 1.0 / 24.0, C2 = -1.0 / 720.0;
+    const double t = SDRX_FMA(x, SDRX_SINCOS_INV_STEP, MAGIC);
+    const double fn = t - MAGIC;
+    unsigned long long tb;
+    __builtin_memcpy(&tb, &t, sizeof(tb));
+    const unsigned k = (unsigned)tb & (SDRX_SINCOS_TAB_N - 1); /* fn mod 256 (two's complement: right for negative fn too) */
     const double Sk = tab[2 * k], Ck = tab[2 * k + 1];
+    const double r = SDRX_FMA(-fn, SDRX_SINCOS_Q2, SDRX_FMA(-fn, SDRX_SINCOS_Q1, x));
     const double z = r * r;
-    double ps = SDRX_FMA(z, S3, S2);
-    ps = SDRX_FMA(z, ps, S1);
+    const double ps = SDRX_FMA(z, S2, S1);
     const double sr = SDRX_FMA(z * r, ps, r); /* sin r */
-    double pc = SDRX_FMA(z, C3, C2);
-    pc = SDRX_FMA(z, pc, C1);
+    double pc = SDRX_FMA(z, C2, C1);
     pc = SDRX_FMA(z, pc, -0.5);
     const double cm = z * pc; /* cos r - 1 */
-    *s = Sk + SDRX_FMA(Sk, cm, Ck * sr);
-    *c = Ck + SDRX_FMA(Ck, cm, -(Sk * sr));
+    *s = SDRX_FMA(Ck, sr, SDRX_FMA(Sk, cm, Sk)); /* S_k cos r + C_k sin r: two roundings */
+    *c = SDRX_FMA(-Sk, sr, SDRX_FMA(Ck, cm, Ck));
     return !(__builtin_fabs(x) <= 1.5e6);
 }
 

@@ -63,14 +63,41 @@ const double RRC_COEFF[129] = {SDRX_RRC_VALUES};
 
 #define SDRX_SGN(v) (((v) == 0.0) ? 0.0 : (((v) < 0.0) ? -1.0 : 1.0)) /* BPSK.h:16 */
 
+// What a speculative block of the loops watches instead of branching: a block takes the straight-line common case of
+// SIGN_FUNC and of sincos, and is repeated with the general forms if anything it met was outside that case (silence, a
+// stream's zero padding, a loop that has run away): psk_loops_split_kernel, psk_loops_tri_kernel.
+struct SpecWatch {
+    double zmin = 1.0;  // smallest magnitude a sign was taken of in the carrier loop
+    double amax = 0.0;  // largest magnitude handed to sincos
+    bool odd = false;   // the timing loop took the sign of a zero or a NaN
+    __device__ __forceinline__ bool raised() const { return odd || !(zmin > 0.0) || !(amax <= 1.5e6); }
+};
+
+// SIGN_FUNC (BPSK.h:16).  For every v that is neither a zero nor a NaN it is 1.0 with v's sign: one bit-field insert instead
+// of two compares and two selects on the loops' serial chain.
+//  * carrier loop (NAN_MATTERS = false): 8 (sgn(ti) tr - sgn(tr) ti) is a NaN whenever tr or ti is, whatever the signs are
+//    taken to be, so only zeros have to be caught: the smallest |v| of the block (one v_min_f64 per sign, no scalar work).
+//  * timing loop (NAN_MATTERS = true): the detector multiplies OLDER samples by the new sample's sign, so a NaN's sign
+//    must be +1 as SIGN_FUNC has it: the caller tests the product of the two rails' new samples for zero / NaN once per step.
+template <bool SPECULATE, bool NAN_MATTERS> __device__ __forceinline__ double sgn_of(double v, SpecWatch &w)
+{
+    if constexpr (SPECULATE) {
+        if constexpr (!NAN_MATTERS) w.zmin = __builtin_fmin(w.zmin, __builtin_fabs(v));
+        return __builtin_copysign(1.0, v);
+    } else {
+        return SDRX_SGN(v);
+    }
+}
+
 // ------------------------------------------------------------------------------------- loops
 
-static __device__ const double d_sincos_tab[128] = {SDRX_SINCOS_TAB_VALUES};
+constexpr int SINCOS_TAB_DOUBLES = 2 * SDRX_SINCOS_TAB_N;
+static __device__ const double d_sincos_tab[SINCOS_TAB_DOUBLES] = {SDRX_SINCOS_TAB_VALUES};
 
-// the workgroup's copy of sdrx_sincos_tab's table (1 KB); the caller puts a barrier behind it
+// the workgroup's copy of sdrx_sincos_tab's table (4 KB); the caller puts a barrier behind it
 __device__ __forceinline__ void sincos_table_to_lds(double *tab)
 {
-    for (unsigned i = threadIdx.x; i < 128; i += blockDim.x) tab[i] = d_sincos_tab[i];
+    for (unsigned i = threadIdx.x; i < SINCOS_TAB_DOUBLES; i += blockDim.x) tab[i] = d_sincos_tab[i];
 }
 
 struct Interp {
@@ -135,31 +162,51 @@ __device__ __forceinline__ void timing_step(TimingState &t, double &re, double &
     im = t.reg_I;
 }
 
+// The output lookup on a de-rotated sample (tr, ti).
+template <int KIND> __device__ __forceinline__ int psk_decision(double tr, double ti)
+{
+    if constexpr (KIND == SDRX_BPSK) {
+        return (tr < 0.0) ? 1 : 0; // BPSK.cpp:413-421: SIGN_FUNC(tr) < 0 is tr < 0 (a NaN has sign +1: neither)
+    } else {
+        // QPSK.cpp:396-414 compares the two SIGN_FUNC values; written on the samples themselves: sign < 0 is v < 0,
+        // sign > 0 is !(v < 0) && !(v == 0) (which holds for a NaN, whose SIGN_FUNC is +1)
+        const bool rn = tr < 0.0, in = ti < 0.0;
+        const bool rp = !rn && !(tr == 0.0), ip = !in && !(ti == 0.0);
+        return (rn && in) ? 3 : ((rp && in) ? 2 : ((rn && ip) ? 1 : 0));
+    }
+}
+
 // One sample through phase_shift_correction + the output lookup; returns the decision.
-// SPECULATE: only sincos's straight-line common case runs and `rare` collects its "argument out of range" flag: the
-// caller repeats the block without SPECULATE if any lane raised it (sdrx_math.h: sdrx_sincos_core).
-// cos / sin: sdrx_sincos_tab (include/sdrx_math.h), its 64-entry table in LDS (`tab`: sincos_table_to_lds).
+// SPECULATE: only the straight-line common cases of sincos and SIGN_FUNC run and `watch` collects what would leave them;
+// the caller repeats the block without SPECULATE if any lane's watch is raised (SpecWatch; sdrx_math.h: sdrx_sincos_tab_core).
+// cos / sin: sdrx_sincos_tab (include/sdrx_math.h), its 256-entry table in LDS (`tab`: sincos_table_to_lds).
 template <int KIND, bool SPECULATE = false>
-__device__ __forceinline__ int phase_step(PhaseState &p, double re, double im, const double *tab, bool *rare = nullptr)
+__device__ __forceinline__ int phase_step(PhaseState &p, double re, double im, const double *tab, SpecWatch *watch = nullptr)
 {
     const double PK1 = 0.0620001240002480, PK2 = 0.000992001984003968; // BPSK.cpp:424-432
     double sn, cs;
+    SpecWatch unused;
+    SpecWatch &flag = SPECULATE ? *watch : unused;
     auto sincos_of = [&](double a) {
-        if constexpr (SPECULATE) *rare |= sdrx_sincos_tab_core(a, tab, &sn, &cs) != 0;
-        else sdrx_sincos_tab(a, tab, &sn, &cs);
+        if constexpr (SPECULATE) {
+            (void)sdrx_sincos_tab_core(a, tab, &sn, &cs);
+            flag.amax = __builtin_fmax(flag.amax, __builtin_fabs(a)); // (a NaN is not kept: it comes out of both forms as a NaN)
+        } else {
+            sdrx_sincos_tab(a, tab, &sn, &cs);
+        }
     };
     if constexpr (KIND == SDRX_BPSK) { // BPSK.cpp:399-411
         sincos_of(p.dds_delay + p.temp);
         p.dds_delay = p.dds_delay + p.temp;
         p.tr = re * cs - im * sn;
         p.ti = im * cs + re * sn;
-        const double val = 8.0 * (SDRX_SGN(p.ti) * p.tr - SDRX_SGN(p.tr) * p.ti);
+        const double val = 8.0 * (sgn_of<SPECULATE, false>(p.ti, flag) * p.tr - sgn_of<SPECULATE, false>(p.tr, flag) * p.ti);
         p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
         p.plf_x = val;
         p.plf_y = p.temp;
-        return (p.tr < 0.0) ? 1 : 0; // SIGN_FUNC(tr) < 0 is tr < 0 (a NaN has sign +1: neither)
+        return psk_decision<KIND>(p.tr, p.ti);
     } else { // QPSK.cpp:361-373: loop filter first, from the previous product
-        const double val = 8.0 * (SDRX_SGN(p.ti) * p.tr - SDRX_SGN(p.tr) * p.ti);
+        const double val = 8.0 * (sgn_of<SPECULATE, false>(p.ti, flag) * p.tr - sgn_of<SPECULATE, false>(p.tr, flag) * p.ti);
         p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
         p.plf_x = val;
         p.plf_y = p.temp;
@@ -167,12 +214,7 @@ __device__ __forceinline__ int phase_step(PhaseState &p, double re, double im, c
         p.dds_delay = p.dds_delay + p.temp;
         p.tr = re * cs - im * sn;
         p.ti = im * cs + re * sn;
-        // QPSK.cpp:396-414 compares the two SIGN_FUNC values; written on the samples themselves so that the compares
-        // the next step's SIGN_FUNCs need anyway are the only ones: sign < 0 is v < 0, sign > 0 is !(v < 0) && !(v == 0)
-        // (which holds for a NaN, whose SIGN_FUNC is +1)
-        const bool rn = p.tr < 0.0, in = p.ti < 0.0;
-        const bool rp = !rn && !(p.tr == 0.0), ip = !in && !(p.ti == 0.0);
-        return (rn && in) ? 3 : ((rp && in) ? 2 : ((rn && ip) ? 1 : 0));
+        return psk_decision<KIND>(p.tr, p.ti);
     }
 }
 
@@ -190,7 +232,7 @@ __global__ void __launch_bounds__(64) psk_loops_kernel(double2 *__restrict__ mf,
                                                        sdrx_psk_state *__restrict__ states, uint8_t *__restrict__ dec,
                                                        size_t out_pitch, double *__restrict__ carry, int piece)
 {
-    __shared__ __align__(16) double tab[128];
+    __shared__ __align__(16) double tab[SINCOS_TAB_DOUBLES];
     if constexpr (PHASE) {
         sincos_table_to_lds(tab);
         __syncthreads();
@@ -283,7 +325,7 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
                                                               double *__restrict__ carry, int piece)
 {
     __shared__ double2 ring[2][SPLIT_KB][64];
-    __shared__ __align__(16) double tab[128];
+    __shared__ __align__(16) double tab[SINCOS_TAB_DOUBLES];
     sincos_table_to_lds(tab); // (the first barrier of the block loop below comes before the carrier wave's first step)
     __builtin_amdgcn_s_setprio(3); // latency-bound chains: issue ahead of a throughput kernel sharing the SIMD
     const unsigned lane = threadIdx.x & 63;
@@ -313,13 +355,13 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
             ring[j & 1][k][lane] = make_double2(re, im);
         }
     };
-    auto carrier_block = [&](auto full, auto speculate, size_t jb, bool &rare) {
+    auto carrier_block = [&](auto full, auto speculate, size_t jb, SpecWatch &watch) {
         const size_t i0 = jb * SPLIT_KB;
 #pragma unroll
         for (int k = 0; k < SPLIT_KB; k++) {
             const double2 v = ring[jb & 1][k][lane];
             if (decltype(full)::value || i0 + k < m) {
-                const int decision = phase_step<KIND, decltype(speculate)::value>(p, v.x, v.y, tab, &rare);
+                const int decision = phase_step<KIND, decltype(speculate)::value>(p, v.x, v.y, tab, &watch);
                 if ((k & 1) == 0 && active) d[(i0 + k) >> 1] = (uint8_t)decision; // SPLIT_KB is even: parity of k
             }
         }
@@ -353,12 +395,12 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
             // away: never in normal operation) the block is repeated from the saved state through the full function,
             // which returns the same values for every lane that was inside
             const PhaseState p0 = p;
-            bool rare = false;
-            if (j * SPLIT_KB <= m) carrier_block(yes_t(), yes_t(), j - 1, rare);
-            else carrier_block(no_t(), yes_t(), j - 1, rare);
-            if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+            SpecWatch watch;
+            if (j * SPLIT_KB <= m) carrier_block(yes_t(), yes_t(), j - 1, watch);
+            else carrier_block(no_t(), yes_t(), j - 1, watch);
+            if (__builtin_amdgcn_ballot_w64(watch.raised()) != 0) {
                 p = p0;
-                carrier_block(no_t(), no_t(), j - 1, rare);
+                carrier_block(no_t(), no_t(), j - 1, watch);
             }
         }
         __syncthreads();
@@ -406,20 +448,33 @@ __device__ __forceinline__ InterpPrefix interp_prefix(Interp &d, double in)
     return r;
 }
 
-// timing_step with the interpolator's prefix already done (q, i: rails "Q" and "I" of this sample)
-__device__ __forceinline__ void timing_step_tail(TimingState &t, const InterpPrefix &q, const InterpPrefix &i, double &re, double &im)
+// The Gardner detector's SIGN_FUNC values of g1 .. g4, carried beside them: each is the sign of an interpolator output
+// taken once, when that output was new (the detector of BPSK.cpp:346-363 takes it again one and two samples later).
+struct GardnerSigns { double s1, s2, s3, s4; };
+
+// timing_step with the interpolator's prefix already done (q, i: rails "Q" and "I" of this sample).
+// SPECULATE: see sgn_of.
+template <bool SPECULATE>
+__device__ __forceinline__ void timing_step_tail(TimingState &t, GardnerSigns &gs, const InterpPrefix &q, const InterpPrefix &i,
+                                                 double &re, double &im, SpecWatch &watch)
 {
     const double strobe = (t.nco < 0) ? 1.0 : 0.0;
     t.reg_mu = (strobe >= 1) ? t.mu_delay * 2 : t.reg_mu;
     const double mu = t.reg_mu;
     const double V7q = q.V3 * mu + q.V6, Q = q.d5 + mu * V7q;
     const double V7i = i.V3 * mu + i.V6, I = i.d5 + mu * V7i;
-    const double eg = (t.g3 * (-SDRX_SGN(Q) + SDRX_SGN(t.g4)) + (t.g1 * (-SDRX_SGN(I) + SDRX_SGN(t.g2))));
+    const double sQ = sgn_of<SPECULATE, true>(Q, watch), sI = sgn_of<SPECULATE, true>(I, watch);
+    if constexpr (SPECULATE) watch.odd |= __builtin_amdgcn_class(Q * I, 0x063); // sNaN, qNaN, -0, +0 (a product that underflows: a needless repeat)
+    const double eg = (t.g3 * (-sQ + gs.s4) + (t.g1 * (-sI + gs.s2)));
     const double e = (strobe >= 0.5) ? eg : 0.0;
     t.g2 = t.g1;
     t.g1 = I;
     t.g4 = t.g3;
     t.g3 = Q;
+    gs.s2 = gs.s1;
+    gs.s1 = sI;
+    gs.s4 = gs.s3;
+    gs.s3 = sQ;
     const double K1 = -0.00587880145347487, K2 = -2.35152058138995e-05;
     const double v = t.lf_y + K2 * e + K1 * (e - t.lf_x);
     t.lf_x = e;
@@ -434,7 +489,7 @@ __device__ __forceinline__ void timing_step_tail(TimingState &t, const InterpPre
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(192) psk_loops_tri_kernel(const double2 *__restrict__ mf, size_t m, size_t nchan,
+__global__ void __launch_bounds__(256) psk_loops_tri_kernel(const double2 *__restrict__ mf, size_t m, size_t nchan,
                                                             size_t pitch, sdrx_psk_state *__restrict__ states,
                                                             uint8_t *__restrict__ dec, size_t out_pitch,
                                                             double *__restrict__ carry, int piece)
@@ -442,9 +497,12 @@ __global__ void __launch_bounds__(192) psk_loops_tri_kernel(const double2 *__res
     extern __shared__ __align__(16) unsigned char tri_smem[];
     typedef double2 (*ring_a_t)[TRI_KB][3][64]; // [buffer][sample][(V3q,V6q) | (V3i,V6i) | (d5q,d5i)][lane]
     typedef double2 (*ring_b_t)[TRI_KB][64];    // [buffer][sample][lane]: (reg_Q, reg_I)
+    // (static: its address is a compile-time constant, so a table read's address is the scaled index itself)
+    __shared__ __align__(16) double tab[SINCOS_TAB_DOUBLES];
     ring_a_t ringA = (ring_a_t)tri_smem;
     ring_b_t ringB = (ring_b_t)(tri_smem + sizeof(double2) * 2 * TRI_KB * 3 * 64);
-    double *tab = (double *)(tri_smem + sizeof(double2) * 2 * TRI_KB * 4 * 64);
+    typedef double2 (*ring_c_t)[TRI_KB / 2][64];  // [buffer][even sample][lane]: (tr, ti)
+    ring_c_t ringC = (ring_c_t)(tri_smem + sizeof(double2) * 2 * TRI_KB * 4 * 64);
     sincos_table_to_lds(tab); // (two barriers of the block loop come before the carrier wave's first step)
     __builtin_amdgcn_s_setprio(3);
     const unsigned lane = threadIdx.x & 63;
@@ -461,6 +519,7 @@ __global__ void __launch_bounds__(192) psk_loops_tri_kernel(const double2 *__res
     Interp ii = {st->ii_d[0], st->ii_d[1], st->ii_d[2], st->ii_d[3], st->ii_d[4]};
     TimingState t = {st->nco_delay, st->reg_mu, st->reg_Q, st->reg_I, st->mu_delay, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0},
                      st->g1, st->g2, st->g3, st->g4, st->lf_x, st->lf_y};
+    GardnerSigns gs = {SDRX_SGN(t.g1), SDRX_SGN(t.g2), SDRX_SGN(t.g3), SDRX_SGN(t.g4)};
     PhaseState p = {st->dds_delay, st->plf_x, st->plf_y, 0.0, 0.0, 0.0};
     if (piece & PIECE_NOT_FIRST) { p.tr = carry[4 * c]; p.ti = carry[4 * c + 1]; p.temp = carry[4 * c + 2]; }
 
@@ -481,7 +540,7 @@ __global__ void __launch_bounds__(192) psk_loops_tri_kernel(const double2 *__res
     // nothing else to run while it waits.  (Reading a whole ring block, stale entries past the call's end included, is
     // harmless: their values are never used.)
     constexpr int TRI_PF = 3;
-    auto timing_block = [&](auto full, size_t j) {
+    auto timing_block = [&](auto full, auto speculate, size_t j, SpecWatch &watch) {
         double2 a[TRI_KB], b[TRI_KB], dd[TRI_KB];
 #pragma unroll
         for (int k = 0; k < TRI_PF; k++) { a[k] = ringA[j & 1][k][0][lane]; b[k] = ringA[j & 1][k][1][lane]; dd[k] = ringA[j & 1][k][2][lane]; }
@@ -495,22 +554,45 @@ __global__ void __launch_bounds__(192) psk_loops_tri_kernel(const double2 *__res
             if (decltype(full)::value || j * TRI_KB + k < m) {
                 const InterpPrefix q = {a[k].x, a[k].y, dd[k].x}, i = {b[k].x, b[k].y, dd[k].y};
                 double re, im;
-                timing_step_tail(t, q, i, re, im);
+                timing_step_tail<decltype(speculate)::value>(t, gs, q, i, re, im, watch);
                 ringB[j & 1][k][lane] = make_double2(re, im);
             }
         }
     };
-    auto carrier_block = [&](auto full, auto speculate, size_t jb, bool &rare) {
+    // The de-rotated samples the decisions are taken of (every second one: BPSK.cpp:413-421's decimate-by-2) go back to
+    // a fourth wave through ring C: the lookup and, above all, the stores -- 64 lanes, 64 cache lines -- cost the carrier
+    // wave a quarter of its time (profiles/r03_tri_prof.txt).
+    auto carrier_block = [&](auto full, auto speculate, size_t jb, SpecWatch &watch) {
         const size_t i0 = jb * TRI_KB;
         double2 v[TRI_KB];
 #pragma unroll
-        for (int k = 0; k < TRI_KB; k++) v[k] = ringB[jb & 1][k][lane]; // (nothing is written to LDS by this wave: all up front)
+        for (int k = 0; k < TRI_KB; k++) v[k] = ringB[jb & 1][k][lane];
 #pragma unroll
         for (int k = 0; k < TRI_KB; k++) {
             if (decltype(full)::value || i0 + k < m) {
-                const int decision = phase_step<KIND, decltype(speculate)::value>(p, v[k].x, v[k].y, tab, &rare);
-                if ((k & 1) == 0 && active) d[(i0 + k) >> 1] = (uint8_t)decision; // TRI_KB is even: parity of k
+                (void)phase_step<KIND, decltype(speculate)::value>(p, v[k].x, v[k].y, tab, &watch);
+                if ((k & 1) == 0) ringC[jb & 1][k >> 1][lane] = make_double2(p.tr, p.ti); // TRI_KB is even: parity of k
             }
+        }
+    };
+    // decisions of block jb: eight per lane, one 8-byte store where the row allows it
+    const bool row_aligned = (((size_t)d) & 7) == 0;
+    auto decision_block = [&](size_t jb) {
+        const size_t i0 = jb * TRI_KB;
+        unsigned w[2] = {0u, 0u};
+#pragma unroll
+        for (int k2 = 0; k2 < TRI_KB / 2; k2++) {
+            const double2 v = ringC[jb & 1][k2][lane]; // (entries past the call's end: stale, not stored)
+            w[k2 >> 2] |= (unsigned)psk_decision<KIND>(v.x, v.y) << (8 * (k2 & 3));
+        }
+        if (!active) return;
+        uint8_t *o = d + (i0 >> 1);
+        if (i0 + TRI_KB <= m && row_aligned) {
+            *(uint2 *)o = make_uint2(w[0], w[1]);
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < TRI_KB / 2; k2++)
+                if (i0 + 2 * k2 < m) o[k2] = (uint8_t)(w[k2 >> 2] >> (8 * (k2 & 3)));
         }
     };
     typedef std::integral_constant<bool, true> yes_t;
@@ -520,9 +602,16 @@ __global__ void __launch_bounds__(192) psk_loops_tri_kernel(const double2 *__res
 #pragma unroll
         for (int k = 0; k < TRI_KB; k++) nxt[k] = ((size_t)k < m) ? x[k] : make_double2(0.0, 0.0);
     }
-    // iteration j: wave 0 on block j, wave 1 on block j-1, wave 2 on block j-2; one barrier per iteration.  A ring buffer
-    // written in iteration j is read in iteration j+1 and written again in j+2: two buffers each.
-    for (size_t j = 0; j < nblocks + 2; j++) {
+    // iteration j: wave 0 on block j, wave 1 on block j-1, wave 2 on block j-2, wave 3 on the decisions of block j-3; one
+    // barrier per iteration.  A ring buffer written in iteration j is read in iteration j+1 and written again in j+2: two
+    // buffers each.
+#ifdef SDRX_TRI_PROFILE // profiles/probes/tri_prof.hip: where each wave's time goes (never defined in the library)
+    long long prof_work = 0, prof_wait = 0, prof_replays = 0;
+#endif
+    for (size_t j = 0; j < nblocks + 3; j++) {
+#ifdef SDRX_TRI_PROFILE
+        const long long prof_t0 = __builtin_amdgcn_s_memtime();
+#endif
         if (role == 0) {
             if (j < nblocks) {
                 double2 cur[TRI_KB];
@@ -539,22 +628,44 @@ __global__ void __launch_bounds__(192) psk_loops_tri_kernel(const double2 *__res
                 if (nb <= m) prefix_block(yes_t(), cur, j);
                 else prefix_block(no_t(), cur, j);
             }
+        } else if (role == 3) {
+            if (j >= 3) decision_block(j - 3);
         } else if (role == 1) {
             if (j >= 1 && j - 1 < nblocks) {
-                if (j * TRI_KB <= m) timing_block(yes_t(), j - 1);
-                else timing_block(no_t(), j - 1);
+                const TimingState t0 = t; // (speculation on the signs' common case: sgn_of)
+                const GardnerSigns gs0 = gs;
+                SpecWatch watch;
+                if (j * TRI_KB <= m) timing_block(yes_t(), yes_t(), j - 1, watch);
+                else timing_block(no_t(), yes_t(), j - 1, watch);
+                if (__builtin_amdgcn_ballot_w64(watch.raised()) != 0) {
+                    t = t0;
+                    gs = gs0;
+                    timing_block(no_t(), no_t(), j - 1, watch);
+                }
             }
-        } else if (j >= 2) {
-            const PhaseState p0 = p; // (speculation on sincos's common case: see psk_loops_split_kernel)
-            bool rare = false;
-            if ((j - 1) * TRI_KB <= m) carrier_block(yes_t(), yes_t(), j - 2, rare);
-            else carrier_block(no_t(), yes_t(), j - 2, rare);
-            if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+        } else if (role == 2 && j >= 2 && j - 2 < nblocks) {
+            const PhaseState p0 = p; // (speculation on the common case of sincos and of the signs: SpecWatch)
+            SpecWatch watch;
+            if ((j - 1) * TRI_KB <= m) carrier_block(yes_t(), yes_t(), j - 2, watch);
+            else carrier_block(no_t(), yes_t(), j - 2, watch);
+            if (__builtin_amdgcn_ballot_w64(watch.raised()) != 0) {
                 p = p0;
-                carrier_block(no_t(), no_t(), j - 2, rare);
+                carrier_block(no_t(), no_t(), j - 2, watch);
             }
         }
+#ifdef SDRX_TRI_PROFILE
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the block's own LDS traffic counts as work
+        const long long prof_t1 = __builtin_amdgcn_s_memtime();
         __syncthreads();
+        prof_work += prof_t1 - prof_t0;
+        prof_wait += (long long)__builtin_amdgcn_s_memtime() - prof_t1;
+    }
+    if (blockIdx.x == 0 && lane == 0)
+        printf("role %u: work %lld wait %lld ticks over %zu iterations (%zu samples)\n", role, prof_work, prof_wait, nblocks + 3, m);
+    {
+#else
+        __syncthreads();
+#endif
     }
     if (!active) return;
     if (role == 0) {
@@ -564,12 +675,12 @@ __global__ void __launch_bounds__(192) psk_loops_tri_kernel(const double2 *__res
         st->nco_delay = t.nco; st->reg_mu = t.reg_mu; st->reg_Q = t.reg_Q; st->reg_I = t.reg_I; st->mu_delay = t.mu_delay;
         st->g1 = t.g1; st->g2 = t.g2; st->g3 = t.g3; st->g4 = t.g4;
         st->lf_x = t.lf_x; st->lf_y = t.lf_y;
-    } else {
+    } else if (role == 2) {
         st->dds_delay = p.dds_delay; st->plf_x = p.plf_x; st->plf_y = p.plf_y;
         if (piece & PIECE_NOT_LAST) { carry[4 * c] = p.tr; carry[4 * c + 1] = p.ti; carry[4 * c + 2] = p.temp; }
     }
 }
-constexpr size_t TRI_LDS_BYTES = sizeof(double2) * 2 * TRI_KB * 4 * 64 + 128 * sizeof(double);
+constexpr size_t TRI_LDS_BYTES = sizeof(double2) * 2 * (TRI_KB * 4 + TRI_KB / 2) * 64; // the rings (dynamic); + the 4 KB table (static)
 
 int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_pitch, sdrx_psk_state *states,
                      uint8_t *decisions, size_t out_pitch, int run_timing, int run_phase, hipStream_t s, double *carry,
@@ -597,7 +708,7 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
         typedef void (*tri_fn)(const double2 *, size_t, size_t, size_t, sdrx_psk_state *, uint8_t *, size_t, double *, int);
         tri_fn fn = kind == SDRX_BPSK ? (tri_fn)psk_loops_tri_kernel<SDRX_BPSK> : (tri_fn)psk_loops_tri_kernel<SDRX_QPSK>;
         SDRX_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRI_LDS_BYTES));
-        hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(192), TRI_LDS_BYTES, s, (const double2 *)mf_iq, m, nchan, mf_pitch, states,
+        hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), TRI_LDS_BYTES, s, (const double2 *)mf_iq, m, nchan, mf_pitch, states,
                            decisions, out_pitch, carry, piece);
         SDRX_HIP(hipGetLastError());
         note_kernel("psk_loops_tri_kernel", kind, 0, 0, 0);
