@@ -1791,8 +1791,8 @@ def test_fir_job_n_before_tiles_a_stream_in_time():
 
 
 def test_psk_carrier_loop_outside_the_common_range_of_sincos(tune):
-    """The split kernel runs each 16-sample block of the carrier loop on sincos's straight-line common case
-    (|phase| <= 1.5e6) and repeats the block through the full function if any lane left it.  Channels that start
+    """The split and three-wave kernels run each block of the carrier loop on sincos's straight-line common case
+    (|phase| <= 1.5e6) and repeat the block through the full function if any lane left it.  Channels that start
     near the limit (and cross it inside a block), far beyond it, at an absurd phase, and one fed an infinite sample
     give the oracle's decisions and loop state bit for bit (NaNs in the same places), in both kernel forms, next to
     ordinary channels in the same wave."""
@@ -1811,7 +1811,7 @@ def test_psk_carrier_loop_outside_the_common_range_of_sincos(tune):
             st.dds_delay = starts[c]
             wants.append([O.psk_demodulate(st, iqs[c]) for _ in range(2)])
             sts.append(st)
-        for force in ("1", "0"):
+        for force in ("2", "1", "0"):
             tune("SDRX_PSK_SPLIT", force)
             b = device.PskBank(lk, nchan, n)
             rows = b.states.cpu().numpy().copy()
@@ -1827,6 +1827,52 @@ def test_psk_carrier_loop_outside_the_common_range_of_sincos(tune):
             for c in range(nchan):
                 assert np.array_equal(hs[c][: 8 * 24].view(np.float64), sts[c].loop_state(), equal_nan=True), (kind, force, c)
         assert np.isnan(sts[6].loop_state()).any() and not np.isnan(sts[7].loop_state()).any()
+
+
+def _same_bits_or_both_nan(a, b):
+    a, b = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    return bool(np.all((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_psk_loops_signs_of_zeros_and_nans_in_every_kernel_form(tune):
+    """The loops' speculative blocks take SIGN_FUNC as 1.0 with the operand's sign and are repeated with the real
+    three-valued function when a block met a zero (carrier and timing loop) or a NaN (timing loop, whose detector
+    multiplies OLDER samples by the new sign).  Channels of silence, of signal with silent stretches (the matched
+    filter's output becomes exactly zero 129 samples in), of negative zeros, with a NaN and with an infinite sample,
+    next to ordinary ones in the same wave: decisions equal the oracle's and the 24 loop-state doubles are the same
+    BITS (the sign of a zero included; NaNs in the same places), over two calls, in all three kernel forms."""
+    n = 4096
+    for kind, lk in ((O.QPSK, _lib.QPSK), (O.BPSK, _lib.BPSK)):
+        iqs = [np.asarray(psk_test_signal(kind, n // 8, seed=700 + c, phase_deg=50.0 * c, snr_db=14.0, timing_offset=c % 4),
+                          dtype=np.float64).copy() for c in range(10)]
+        iqs[1][:] = 0.0                      # silence
+        iqs[2][2 * 1000: 2 * 1700] = 0.0     # a silent stretch: zeros reach the loops, then signal again
+        iqs[3][: 2 * 700] = 0.0              # zero padding in front
+        iqs[4][2 * 1500 + 1] = np.nan        # one NaN on the Q rail
+        iqs[5][:] = -0.0                     # negative zeros
+        iqs[6][2 * 900] = -np.inf
+        iqs[7][1::2] = 0.0                   # one rail silent throughout
+        iqs[8][2 * 2048:] = 0.0              # silent from the middle of the call on
+        nchan = len(iqs)
+        x = torch.tensor(np.stack([z.reshape(-1, 2) for z in iqs]), device="cuda")
+        sts, wants = [], []
+        for c in range(nchan):
+            st = O.psk_new(kind, math_mode=O.MATH_SHARED)
+            wants.append([O.psk_demodulate(st, iqs[c]) for _ in range(2)])
+            sts.append(st)
+        for force in ("2", "1", "0"):
+            tune("SDRX_PSK_SPLIT", force)
+            b = device.PskBank(lk, nchan, n)
+            for blk in range(2):
+                o = torch.zeros(nchan, b.n_dec, dtype=torch.uint8, device="cuda")
+                b.demod(x, o)
+                got = o.cpu().numpy()
+                for c in range(nchan):
+                    assert np.array_equal(got[c][: wants[c][blk].size], wants[c][blk]), (kind, force, blk, c)
+            hs = b.states.cpu().numpy()
+            for c in range(nchan):
+                assert _same_bits_or_both_nan(hs[c][: 8 * 24].view(np.float64), sts[c].loop_state()), (kind, force, c)
+        assert np.isnan(sts[4].loop_state()).any() and not np.isnan(sts[9].loop_state()).any()
 
 
 @pytest.mark.parametrize("kind,lk", [(O.BPSK, _lib.BPSK), (O.QPSK, _lib.QPSK)])
