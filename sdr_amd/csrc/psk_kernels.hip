@@ -200,14 +200,28 @@ __device__ __forceinline__ int phase_step(PhaseState &p, double re, double im, c
         p.dds_delay = p.dds_delay + p.temp;
         p.tr = re * cs - im * sn;
         p.ti = im * cs + re * sn;
-        const double val = 8.0 * (sgn_of<SPECULATE, false>(p.ti, flag) * p.tr - sgn_of<SPECULATE, false>(p.tr, flag) * p.ti);
-        p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
+        const double dif = sgn_of<SPECULATE, false>(p.ti, flag) * p.tr - sgn_of<SPECULATE, false>(p.tr, flag) * p.ti;
+        const double val = 8.0 * dif;
+        // (PK1 + PK2) * (8 dif) and (8 (PK1 + PK2)) * dif are the same real product rounded once -- the same double -- as
+        // long as 8 dif itself does not overflow; the second form keeps the scaling off the serial chain.  An overflow
+        // leaves val = +-inf in plf_x, the next step's loop-filter output is infinite and so is the sincos argument made of
+        // it (amax); what a block's last two steps leave behind is covered by the test of plf_x and plf_y where the
+        // block's watch is read (carrier_block's callers).
+        if constexpr (SPECULATE) p.temp = p.plf_y - PK1 * p.plf_x + (8.0 * (PK1 + PK2)) * dif;
+        else p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
         p.plf_x = val;
         p.plf_y = p.temp;
         return psk_decision<KIND>(p.tr, p.ti);
     } else { // QPSK.cpp:361-373: loop filter first, from the previous product
-        const double val = 8.0 * (sgn_of<SPECULATE, false>(p.ti, flag) * p.tr - sgn_of<SPECULATE, false>(p.tr, flag) * p.ti);
-        p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
+        const double dif = sgn_of<SPECULATE, false>(p.ti, flag) * p.tr - sgn_of<SPECULATE, false>(p.tr, flag) * p.ti;
+        const double val = 8.0 * dif;
+        // (PK1 + PK2) * (8 dif) and (8 (PK1 + PK2)) * dif are the same real product rounded once -- the same double -- as
+        // long as 8 dif itself does not overflow; the second form keeps the scaling off the serial chain.  An overflow
+        // leaves val = +-inf in plf_x, the next step's loop-filter output is infinite and so is the sincos argument made of
+        // it (amax); what a block's last two steps leave behind is covered by the test of plf_x and plf_y where the
+        // block's watch is read (carrier_block's callers).
+        if constexpr (SPECULATE) p.temp = p.plf_y - PK1 * p.plf_x + (8.0 * (PK1 + PK2)) * dif;
+        else p.temp = p.plf_y - PK1 * p.plf_x + (PK1 + PK2) * val;
         p.plf_x = val;
         p.plf_y = p.temp;
         sincos_of(p.dds_delay + p.temp);
@@ -398,7 +412,7 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
             SpecWatch watch;
             if (j * SPLIT_KB <= m) carrier_block(yes_t(), yes_t(), j - 1, watch);
             else carrier_block(no_t(), yes_t(), j - 1, watch);
-            if (__builtin_amdgcn_ballot_w64(watch.raised()) != 0) {
+            if (__builtin_amdgcn_ballot_w64(watch.raised() || !(__builtin_fabs(p.plf_x) <= 1.0e300) || !(__builtin_fabs(p.plf_y) <= 1.0e300)) != 0) {
                 p = p0;
                 carrier_block(no_t(), no_t(), j - 1, watch);
             }
@@ -648,7 +662,7 @@ __global__ void __launch_bounds__(256) psk_loops_tri_kernel(const double2 *__res
             SpecWatch watch;
             if ((j - 1) * TRI_KB <= m) carrier_block(yes_t(), yes_t(), j - 2, watch);
             else carrier_block(no_t(), yes_t(), j - 2, watch);
-            if (__builtin_amdgcn_ballot_w64(watch.raised()) != 0) {
+            if (__builtin_amdgcn_ballot_w64(watch.raised() || !(__builtin_fabs(p.plf_x) <= 1.0e300) || !(__builtin_fabs(p.plf_y) <= 1.0e300)) != 0) {
                 p = p0;
                 carrier_block(no_t(), no_t(), j - 2, watch);
             }
