@@ -608,12 +608,12 @@ def worker(args):
 
 
 def extra_configs(torch, args, dev, L):
-    """cfg1 / cfg3 (QPSK and BPSK) / cfg4 (the N = 1 point of the sharded curve) / cfg5 (VALU exact, MFMA), a few steps
+    """cfg1 (fp64 samples, and the radio's raw bytes) / cfg3 (QPSK and BPSK) / cfg4 (the N = 1 point of the sharded curve) / cfg5 (VALU exact, MFMA), a few steps
     each, so that the driver's box times them too.  Each entry: Msamples/s, ms per launch, fractions of the roofs."""
     out = {}
     # cfg3's 2^26 samples: as 2^14 channels x 2^12 (enough channels to put a wave pair on half of the SIMDs) and as the
     # 1024 channels x 2^16 of SURVEY 8d (16 wave pairs walking 16384 serial loop steps each: latency-bound by design)
-    runs = [("cfg1", []), ("cfg3", []), ("cfg3_bpsk", ["--bpsk"]), ("cfg3_1024ch", ["--channels", "1024"]), ("cfg4", []),
+    runs = [("cfg1", []), ("cfg1_u8", ["--ingest", "u8"]), ("cfg3", []), ("cfg3_bpsk", ["--bpsk"]), ("cfg3_1024ch", ["--channels", "1024"]), ("cfg4", []),
             ("cfg5", []), ("cfg5_exact", ["--exact"])]
     for name, flags in runs:
         a = parse_args(["--workload", name.split("_")[0], "--steps", "50", "--warmup", "20"] + flags)
