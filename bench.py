@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 F64_PEAK_TFLOPS = 78.6  # dense fp64 MFMA peak = fp64 vector FMA peak on MI355X (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
 F32_PEAK_TFLOPS = 157.3  # fp32 vector (packed FMA) peak
+I8_PEAK_TOPS = 5000.0  # dense int8 matrix peak (v_mfma_i32_16x16x64_i8: the guide's dense fp8 figure)
 F64_VALU_2R_TFLOPS = 39.3  # two-rounding arithmetic (separate v_mul_f64 + v_add_f64): one flop per lane and cycle
 
 
@@ -348,10 +349,14 @@ def roofline_of(wl, w, launch_s, kernel):
         tf = w["flop_per_sample"] * w["units"] / launch_s / 1e12
         fma = "fma" in kernel or "mfma" in kernel
         amv = "fir_amv" in kernel
-        peak = F32_PEAK_TFLOPS if amv else (F64_PEAK_TFLOPS if fma else F64_VALU_2R_TFLOPS)
+        i8 = amv and "int8" in kernel
+        peak = I8_PEAK_TOPS if i8 else (F32_PEAK_TFLOPS if amv else (F64_PEAK_TFLOPS if fma else F64_VALU_2R_TFLOPS))
         comp = {"achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                "peak_is": "fp32 packed-FMA vector peak (fp32 filter, decisions verified / recomputed in fp64: bits of the exact path)" if amv
-                else ("fp64 FMA / MFMA peak" if fma else "fp64 VALU peak of two-rounding arithmetic (mul and add issue separately)"),
+                "peak_is": ("int8 matrix-core dense peak; achieved counts the filter's ALGORITHMIC multiply-adds -- the kernel executes six times "
+                            "as many (three 7-bit digit planes of the taps x 128 Toeplitz columns for 64 taps) and is not bound by them: "
+                            "samples as 8-bit integers, decisions verified / recomputed in fp64 (bits of the exact path)") if i8
+                else ("fp32 packed-FMA vector peak (fp32 filter, decisions verified / recomputed in fp64: bits of the exact path)" if amv
+                else ("fp64 FMA / MFMA peak" if fma else "fp64 VALU peak of two-rounding arithmetic (mul and add issue separately)")),
                 "algorithmic_flop_per_sample": w["flop_per_sample"]}
         if wl == "cfg5":  # 2048 flop per 16 B: compute bound; priced against the dense fp64 matrix peak (= the vector FMA peak)
             roof = {"bound": "mfma", "kernel": kernel, "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
