@@ -64,6 +64,8 @@ Tuning &tuning()
         x.amv_stats = env_int("SDRX_AMV_STATS", d.amv_stats);
         x.amv_nb = env_int("SDRX_AMV_NB", d.amv_nb);
         x.amv_dbg = env_int("SDRX_AMV_DBG", d.amv_dbg);
+        x.amv_bytes = env_int("SDRX_AMV_BYTES", d.amv_bytes);
+        x.amv_tpw = env_int("SDRX_AMV_TPW", d.amv_tpw);
         x.fir_fill = env_int("SDRX_FIR_FILL", d.fir_fill);
         x.psk_split = env_int("SDRX_PSK_SPLIT", d.psk_split);
         x.psk_overlap = env_int("SDRX_PSK_OVERLAP", d.psk_overlap);
@@ -181,6 +183,8 @@ extern "C" int sdrx_tune(const char *name, const char *value)
     else if (strcmp(name, "SDRX_AMV_STATS") == 0) t.amv_stats = dflt ? d.amv_stats : v;
     else if (strcmp(name, "SDRX_AMV_NB") == 0) t.amv_nb = dflt ? d.amv_nb : v;
     else if (strcmp(name, "SDRX_AMV_DBG") == 0) t.amv_dbg = dflt ? d.amv_dbg : v;
+    else if (strcmp(name, "SDRX_AMV_BYTES") == 0) t.amv_bytes = dflt ? d.amv_bytes : v;
+    else if (strcmp(name, "SDRX_AMV_TPW") == 0) t.amv_tpw = dflt ? d.amv_tpw : v;
     else if (strcmp(name, "SDRX_FIR_FILL") == 0) t.fir_fill = dflt ? d.fir_fill : v;
     else if (strcmp(name, "SDRX_PSK_SPLIT") == 0) t.psk_split = dflt ? d.psk_split : v;
     else if (strcmp(name, "SDRX_PSK_OVERLAP") == 0) t.psk_overlap = dflt ? d.psk_overlap : v;
@@ -220,7 +224,8 @@ extern "C" const char *sdrx_last_kernel(void)
         else if (strncmp(k.family, "fir_amv_", 8) == 0)
         {
             const bool mm = strncmp(k.family, "fir_amv_mfma", 12) == 0, i8 = strncmp(k.family, "fir_amv_i8", 10) == 0;
-            snprintf(one, sizeof(one), "%s<%s=%d, %s, EPI_AM verified, %s%s>", i8 ? "fir_amv_i8_kernel" : (mm ? "fir_amv_mfma_kernel" : "fir_amv_kernel"),
+            const bool by = strncmp(k.family, "fir_amv_i8_bytes", 16) == 0;
+            snprintf(one, sizeof(one), "%s<%s=%d, %s, EPI_AM verified, %s%s>", by ? "fir_amv_i8_bytes_kernel" : (i8 ? "fir_amv_i8_kernel" : (mm ? "fir_amv_mfma_kernel" : "fir_amv_kernel")),
                      mm || i8 ? "NB" : "R", k.a, lay[k.b & 3],
                      i8 ? "int8 mfma 16x16x64 on 8-bit integer tiles (fixed-point taps), fp32 mfma 16x16x4 on the others" : (mm ? "fp32 mfma 16x16x4" : "fp32 fma"),
                      strstr(k.family, "_ct64") ? ", T=64 compile-time" : "");

@@ -43,6 +43,8 @@ struct Tuning {
     int fir_amv = 1;          // SDRX_FIR_AMV: 0 = sdrx_fir_am_dev never takes the verified fp32 kernels; 1 auto; 2 the packed-fma form; 3 the fp32 matrix-core form; 4 the int8 matrix-core form (where the job has am_work)
     int amv_nb = 2;           // SDRX_AMV_NB: blocks of 256 outputs per wave of fir_amv_mfma_kernel (2 or 4)
     int amv_dbg = 0;          // SDRX_AMV_DBG: timing experiments (wrong results)
+    int amv_bytes = 1;        // SDRX_AMV_BYTES: 0 = raw-byte calls stay on fir_amv_i8_kernel alone (no fir_amv_i8_bytes_kernel)
+    int amv_tpw = 0;          // SDRX_AMV_TPW: tiles per workgroup of fir_amv_i8_bytes_kernel (0 = by call size)
     int amv_stats = 0;        // SDRX_AMV_STATS: 1 = fir_amv_kernel counts its recomputed outputs (sdrx_fir_am_verify_stats)
     int fir_ct = 1;           // SDRX_FIR_CT: 0 = never use the compile-time (T = 129, D = 4) instance of the tile kernel
     int psk_split = -1;       // SDRX_PSK_SPLIT: -1 auto, 0 one-wave loops, 1 two-wave loops, 2 three-wave loops

@@ -28,8 +28,15 @@ while time.time() < t_end:
     nchan = int(rng.choice([1, 1, 2, 3, 5]))
     n = int(rng.choice([1, 37, 2047, 2048, 2049, 4096, 5000, 12345, 40000, 70001]))
     taps = rng.normal(0, 1, T) * np.exp(rng.uniform(-rng.choice([0.0, 3.0, 12.0]), 0, T))
-    kind = rng.choice(["int", "int", "frac", "mixed", "wide"])
-    if kind in ("int", "mixed"):
+    kind = rng.choice(["int", "int", "frac", "mixed", "wide", "bytes", "bytes"])
+    raw = None
+    if kind == "bytes":  # the radio's raw {I, Q} bytes (sample = byte - 127: every byte value, 255 = +128 included)
+        n = int(rng.choice([2048, 4096, 4096 + 8, 40000, 70001, 16 * 2048, 16 * 2048 + 1000]))
+        raw = rng.integers(0, 256, (nchan, n, 2)).astype(np.uint8)
+        if rng.random() < 0.5:
+            raw = (127 + np.clip(np.round(rng.normal(0, 40, (nchan, n, 2))), -127, 128)).astype(np.uint8)
+        re, im = raw[:, :, 0].astype(np.float64) - 127.0, raw[:, :, 1].astype(np.float64) - 127.0
+    elif kind in ("int", "mixed"):
         re = rng.integers(-127, 128, (nchan, n)).astype(np.float64)
         im = rng.integers(-127, 128, (nchan, n)).astype(np.float64)
         if kind == "mixed":
@@ -47,20 +54,26 @@ while time.time() < t_end:
     if med > 0 and np.isfinite(med):
         taps = taps * (80.0 / med)  # the envelope straddles the threshold
     cuts = [0] + sorted(set(int(v) for v in rng.integers(1, max(n, 2), int(rng.integers(0, 3))) if v < n)) + [n]
+    if raw is not None and rng.random() < 0.7:  # rows on 16-byte boundaries: the multi-tile byte kernel takes the inner tiles
+        cuts = sorted(set([0, n] + [int(v) // 8 * 8 for v in cuts[1:-1]]))
     hI = [np.zeros(max(T - 1, 1)) for _ in range(nchan)]
     hQ = [np.zeros(max(T - 1, 1)) for _ in range(nchan)]
     with np.errstate(all="ignore"):
         want = np.stack([np.concatenate([oracle_bits(taps, re[c, a:b], im[c, a:b], hI[c], hQ[c]) for a, b in zip(cuts[:-1], cuts[1:])])
                          for c in range(nchan)])
-    split = bool(rng.random() < 0.3)
+    split = bool(rng.random() < 0.3) and raw is None
     d_re, d_im = torch.tensor(re, device="cuda"), torch.tensor(im, device="cuda")
+    d_raw = torch.tensor(raw, device="cuda") if raw is not None else None
     for form in (1, 2, 3, 4):
         Lx.sdrx_tune(b"SDRX_FIR_AMV", str(form).encode())
         Lx.sdrx_tune(b"SDRX_AMV_NB", b"4" if rng.random() < 0.3 else b"2")
         ch = device.FirChain(taps, nchan=nchan, decim=1)
         got = torch.zeros(nchan, n, dtype=torch.uint8, device="cuda")
         for a, b in zip(cuts[:-1], cuts[1:]):
-            x = (d_re[:, a:b].contiguous(), d_im[:, a:b].contiguous()) if split else torch.stack([d_re[:, a:b], d_im[:, a:b]], dim=-1).contiguous()
+            if d_raw is not None:
+                x = d_raw[:, a:b].contiguous()
+            else:
+                x = (d_re[:, a:b].contiguous(), d_im[:, a:b].contiguous()) if split else torch.stack([d_re[:, a:b], d_im[:, a:b]], dim=-1).contiguous()
             o = torch.zeros(nchan, b - a, dtype=torch.uint8, device="cuda")
             ch.fir_am(x, o)
             got[:, a:b] = o
