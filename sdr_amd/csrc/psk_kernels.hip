@@ -432,15 +432,18 @@ __global__ void __launch_bounds__(128) psk_loops_split_kernel(const double2 *__r
     }
 }
 
-// The same on THREE waves (three SIMDs of a CU).  A lone wave pays about 8 cycles per dependent fp64 instruction and 5 per
-// independent one (profiles/probes/issue_probe.hip), so a loop's step time is its instruction count: the timing wave's 62
-// against the carrier wave's 48 (table sincos).  16 of the 62 -- InterpolationFilter's V1 ... V6 and its delay-line
-// rotation on both rails (BPSK.cpp:323-328,336-341) -- depend on the input samples only, not on mu: wave 0 runs them one
-// ring block ahead and hands (V3, V6, d5) per rail through a second LDS ring; wave 1 finishes the interpolator
-// (V7 = V3*mu + V6; V8 = d5 + mu*V7) and runs the rest of the timing loop; wave 2 is the carrier loop.  The same
-// operations in the same order on the same values: the same bits.  The delay lines live in wave 0 (it stores them back),
-// everything else of the timing state in wave 1.
-constexpr int TRI_KB = 16; // samples per ring block: ring A 96 KB + ring B 32 KB (one workgroup per CU)
+// The same on FOUR waves (the four SIMDs of a CU; the kernel keeps the name it had with three).  A lone wave pays 6 to 8
+// cycles per instruction of a mostly serial stream (profiles/probes/issue_probe.hip, profiles/r03_tri_prof.txt), so a
+// loop's step time is the instruction count of its slowest wave, and the work is cut wherever the recurrences allow:
+//   wave 0  InterpolationFilter's V1 ... V6 and its delay-line rotation on both rails (BPSK.cpp:323-328,336-341): functions of
+//           the input samples only, not of mu; one ring block ahead, (V3, V6, d5) per rail through ring A
+//   wave 1  the rest of the timing loop (V7 = V3*mu + V6; V8 = d5 + mu*V7; detector, loop filter, NCO); (reg_Q, reg_I)
+//           through ring B
+//   wave 2  the carrier loop; every second de-rotated sample through ring C
+//   wave 3  the output lookup and the stores (eight decisions per lane and store)
+// The same operations in the same order on the same values: the same bits.  The delay lines live in wave 0 (it stores
+// them back), the rest of the timing state in wave 1, the carrier state in wave 2.
+constexpr int TRI_KB = 16; // samples per ring block: ring A 96 KB + ring B 32 KB + ring C 16 KB (+ 4 KB sincos table): one workgroup per CU
 
 struct InterpPrefix { double V3, V6, d5; };
 __device__ __forceinline__ InterpPrefix interp_prefix(Interp &d, double in)
@@ -716,7 +719,7 @@ int launch_psk_loops(int kind, double *mf_iq, size_t m, size_t nchan, size_t mf_
     // (the two-wave form holds 64 KB of LDS per workgroup: two per CU, 512 at a time; measured, loops alone, two-wave /
     // one-wave: 2^15 channels 0.125 / 0.181 ms, 2^16 0.128 / 0.119, 2^17 0.146 / 0.115)
     const bool split = split_env >= 0 ? split_env != 0 : blocks <= 512;
-    // the three-wave form (132 KB of LDS: one workgroup per CU) while every workgroup has a CU to itself
+    // the four-wave form (148 KB of LDS: one workgroup per CU) while every workgroup has a CU to itself
     const bool tri = split_env >= 0 ? split_env == 2 : blocks <= 256;
     if (run_timing && run_phase && tri) {
         typedef void (*tri_fn)(const double2 *, size_t, size_t, size_t, sdrx_psk_state *, uint8_t *, size_t, double *, int);
