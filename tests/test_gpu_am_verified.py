@@ -349,3 +349,84 @@ def test_verified_forms_from_the_radios_raw_bytes(T, tune):
     x2 = raw.view(np.int8).astype(np.float64) - 127.4
     w2 = np.stack([_oracle_bits(taps, x2[c, :, 0], x2[c, :, 1]) for c in range(nchan)])
     assert np.array_equal(o.cpu().numpy(), w2)
+
+
+def test_raw_byte_kernel_edges_refused_plans_and_history_in_front(tune):
+    """fir_amv_i8_bytes_kernel takes the tiles inside a raw-byte call whose rows sit on 16-byte boundaries; the first tile
+    and a ragged last one go to fir_amv_i8_kernel on a grid of their own.  Bits equal the oracle's chain on byte - 127
+      * for lengths around the tile (2048) and the edge rules: one tile, two, whole tiles only, a ragged tail, 3 channels
+        with a row pitch wider than the call;
+      * when the plan REFUSES the taps (all zero; a NaN tap; taps so small that the fixed-point scale overflows): every
+        output of the inner tiles is recomputed in the reference's arithmetic;
+      * when the call's history lies in FRONT of it in the same buffer (sdrx_fir_job.n_before): no edge tile at the front."""
+    rng = np.random.default_rng(77)
+    err, taps0 = O.fir_design(O.LPF, 64, 2.0e6, 1.0e5)
+    assert err == 0
+    Lx = _lib.lib()
+    tune("SDRX_FIR_AMV", 4)
+    tune("SDRX_AMV_STATS", 1)
+
+    def raw_rows(nchan, n):
+        raw = np.zeros((nchan, n, 2), dtype=np.uint8)
+        for c in range(nchan):
+            re, im, _ = ook_iq(n, seed=4000 + c + n, ds=8)
+            raw[c, :, 0] = np.round(re).clip(-127, 128) + 127
+            raw[c, :, 1] = np.round(im).clip(-127, 128) + 127
+        raw[:, rng.integers(0, n, 30), rng.integers(0, 2, 30)] = rng.integers(0, 256, 30).astype(np.uint8)[None, :]
+        raw[0, n // 2, 0] = 255
+        return raw
+
+    # ---- lengths and pitches
+    for n, nchan, pitch in ((2048, 1, 2048), (4096, 2, 4096), (8 * 2048, 3, 8 * 2048 + 64), (5 * 2048 + 8 * 31, 2, 5 * 2048 + 8 * 31),
+                            (40 * 2048, 1, 40 * 2048)):
+        raw = raw_rows(nchan, pitch)[:, :, :]
+        x = raw.astype(np.float64) - 127.0
+        want = np.stack([_oracle_bits(taps0, x[c, :n, 0], x[c, :n, 1]) for c in range(nchan)])
+        d_raw = torch.tensor(raw, device="cuda")
+        ch = device.FirChain(taps0, nchan=nchan, decim=1)
+        out = torch.zeros(nchan, n, dtype=torch.uint8, device="cuda")
+        j = ch._job(_lib.IQ_U8, d_raw, None, n, pitch, out, None, n, False, 0)
+        _stats()
+        assert Lx.sdrx_fir_am_dev(C.byref(j)) == 0
+        torch.cuda.synchronize()
+        kern = Lx.sdrx_last_kernel().decode()
+        assert ("fir_amv_i8_bytes_kernel" in kern) == (n > 2048), (n, kern)
+        assert np.array_equal(out.cpu().numpy(), want), (n, nchan, pitch)
+        assert _stats()[3] == nchan * (n // 2048 - 1), (n, "tiles on the int8 path")
+
+    # ---- plans that refuse the taps
+    n, nchan = 6 * 2048, 2
+    raw = raw_rows(nchan, n)
+    x = raw.astype(np.float64) - 127.0
+    d_raw = torch.tensor(raw, device="cuda")
+    nan_taps = taps0.copy()
+    nan_taps[17] = np.nan
+    for name, taps in (("zero", np.zeros(64)), ("nan", nan_taps), ("tiny", taps0 * 1e-306)):
+        with np.errstate(all="ignore"):
+            want = np.stack([_oracle_bits(taps, x[c, :, 0], x[c, :, 1]) for c in range(nchan)])
+        ch = device.FirChain(taps, nchan=nchan, decim=1)
+        out = torch.full((nchan, n), 7, dtype=torch.uint8, device="cuda")
+        _stats()
+        ch.fir_am(d_raw, out)
+        torch.cuda.synchronize()
+        assert "fir_amv_i8_bytes_kernel" in Lx.sdrx_last_kernel().decode(), name
+        assert np.array_equal(out.cpu().numpy(), want), name
+        st = _stats()
+        assert st[3] == 0 and st[0] >= nchan * 4 * 2048, (name, st)  # no tile on the integer path; the inner tiles recomputed
+
+    # ---- history in front of the call
+    N, off, nchan = 12 * 2048, 2048 + 8 * 40, 2
+    raw = raw_rows(nchan, N)
+    x = raw.astype(np.float64) - 127.0
+    want = np.stack([_oracle_bits(taps0, x[c, :, 0], x[c, :, 1]) for c in range(nchan)])[:, off:]
+    d_raw = torch.tensor(raw, device="cuda")
+    ch = device.FirChain(taps0, nchan=nchan, decim=1)
+    out = torch.zeros(nchan, N - off, dtype=torch.uint8, device="cuda")
+    j = ch._job(_lib.IQ_U8, d_raw[:, off:], None, N - off, N, out, None, N - off, False, 0)
+    j.n_before = off
+    _stats()
+    assert Lx.sdrx_fir_am_dev(C.byref(j)) == 0
+    torch.cuda.synchronize()
+    assert "fir_amv_i8_bytes_kernel" in Lx.sdrx_last_kernel().decode()
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert _stats()[3] == nchan * ((N - off) // 2048)  # the first tile is an inner tile here; the ragged last one is not
