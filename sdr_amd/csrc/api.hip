@@ -254,7 +254,11 @@ extern "C" int sdrx_fir_am_verify_stats(uint64_t out[4], int reset)
     if (!d) return SDRX_EHIP;
     SDRX_HIP(hipDeviceSynchronize());
     if (out) SDRX_HIP(hipMemcpy(out, d, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) SDRX_HIP(hipMemset(d, 0, 4 * sizeof(uint64_t)));
+    if (reset) { // (hipMemset on device memory may return before the fill has run, and it runs on the null stream, which
+        // the callers' non-blocking streams do not wait for: wait here)
+        SDRX_HIP(hipMemsetAsync(d, 0, 4 * sizeof(uint64_t), nullptr));
+        SDRX_HIP(hipStreamSynchronize(nullptr));
+    }
     return SDRX_OK;
 }
 
@@ -687,8 +691,11 @@ static int fir_alloc_device(sdrx_fir *f)
     SDRX_HIP(hipMemcpy(f->d_taps, f->taps.data(), f->T * sizeof(double), hipMemcpyHostToDevice));
     for (int i = 0; i < 2; i++) {
         SDRX_HIP(hipMalloc((void **)&f->d_state[i], sd * sizeof(double)));
-        SDRX_HIP(hipMemset(f->d_state[i], 0, sd * sizeof(double)));
+        // on the object's own stream, then waited for (a hipMemset would run on the null stream, which a non-blocking stream
+        // does not wait for, and may return before the fill has run: the first launch could then read the rows too early)
+        SDRX_HIP(hipMemsetAsync(f->d_state[i], 0, sd * sizeof(double), f->stream));
     }
+    SDRX_HIP(hipStreamSynchronize(f->stream));
     return SDRX_OK;
 }
 
@@ -727,8 +734,10 @@ extern "C" void sdrx_fir_get_taps(const sdrx_fir_t *f, double *taps)
 extern "C" void sdrx_fir_reset(sdrx_fir_t *f)
 {
     if (!f || f->err != 0) return; // filt.cpp:241
+    // on the object's own stream (behind whatever it still runs), and done when this returns: sdrx_fir_execute_batch reads
+    // the rows from another object's stream
+    for (int i = 0; i < 2; i++) (void)hipMemsetAsync(f->d_state[i], 0, sdrx_fir_state_doubles(f->T) * sizeof(double), f->stream);
     (void)hipStreamSynchronize(f->stream);
-    for (int i = 0; i < 2; i++) (void)hipMemset(f->d_state[i], 0, sdrx_fir_state_doubles(f->T) * sizeof(double));
 }
 
 extern "C" int sdrx_fir_execute(sdrx_fir_t *f, double *buf, size_t n)
@@ -953,7 +962,7 @@ extern "C" sdrx_fir_ring_t *sdrx_fir_ring_create(const sdrx_fir_job *chunk0, int
     // chunk 0's output slot, which the first replay overwrites.
     const size_t st_bytes = chunk0->nchan * chunk0->state_pitch * (chunk0->dtype == SDRX_F32 ? sizeof(float) : sizeof(double));
     void *tmp = nullptr;
-    bool ok = hipMalloc(&tmp, 2 * st_bytes + 256) == hipSuccess && hipMemset(tmp, 0, 2 * st_bytes + 256) == hipSuccess;
+    bool ok = hipMalloc(&tmp, 2 * st_bytes + 256) == hipSuccess && hipMemsetAsync(tmp, 0, 2 * st_bytes + 256, nullptr) == hipSuccess; // (the launch below is on the null stream too)
     if (ok) {
         sdrx_fir_job w = *chunk0;
         w.state_in = tmp;
@@ -1193,8 +1202,9 @@ extern "C" sdrx_chain_t *sdrx_chain_create(const double *taps, int num_taps, uns
               hipMemcpy(c->d_taps, taps, num_taps * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
     for (int i = 0; ok && i < 2; i++)
         ok = hipMalloc((void **)&c->d_state[i], sd * sizeof(double)) == hipSuccess &&
-             hipMemset(c->d_state[i], 0, sd * sizeof(double)) == hipSuccess &&
+             hipMemsetAsync(c->d_state[i], 0, sd * sizeof(double), c->stream) == hipSuccess && // (ordered before the chain's first launch)
              hipEventCreateWithFlags(&c->slot[i].done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
     if (!ok) {
         set_error("sdrx_chain_create: device allocation failed");
         sdrx_chain_destroy(c);
@@ -1222,8 +1232,8 @@ extern "C" void sdrx_chain_destroy(sdrx_chain_t *c)
 extern "C" void sdrx_chain_reset(sdrx_chain_t *c)
 {
     if (!c) return;
+    for (int i = 0; i < 2; i++) (void)hipMemsetAsync(c->d_state[i], 0, sdrx_fir_state_doubles(c->T) * sizeof(double), c->stream);
     (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 2; i++) (void)hipMemset(c->d_state[i], 0, sdrx_fir_state_doubles(c->T) * sizeof(double));
 }
 
 // re/im: split fp64 rails; or u8 != nullptr: raw interleaved bytes (SDRX_IQ_U8) with bias / flags
